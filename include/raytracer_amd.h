@@ -1,0 +1,244 @@
+/*
+ * raytracer_amd.h -- flat C ABI of the MI355X (gfx950) render path.
+ *
+ * Everything here is plain C: POD structs, pointers and sizes.  The library
+ * behind it (libraytracer_amd.so) is hand-written HIP; it needs a GPU and
+ * returns RT_ERR_NO_DEVICE when there is none (there is no CPU fallback).
+ *
+ * The interface replaces, one for one, what the reference's only device entry
+ * point does for its caller:
+ *
+ *     extern "C" void launch_kernel(TKSceneData *data, ShadingType stype,
+ *                                   int width, int height, uchar4 *output,
+ *                                   int sampleCount);       (kernel.h:30-31)
+ *
+ * launch_kernel itself (same symbol, same argument order) is exported too; it
+ * is declared in raytracer_tokens.h because its first argument is a C++ object.
+ *
+ * Conventions shared with the reference:
+ *   - matrices are 16 floats, column-major (GLM layout): m[col*4 + row];
+ *   - the frame is row-major, index y*width + x, row 0 is the BOTTOM row,
+ *     4 bytes per pixel {r, g, b, 255}                      (kernel.cu:545-570);
+ *   - primitive ids number the BVH primitives in the order the reference
+ *     creates them: spheres, triangles, boxes, smooth triangles, each in
+ *     input order (kernel.cu:419-456); planes follow, id = n_bvh_prims + k
+ *     (planes are not in the BVH: kernel.cu:411-416, bvh.cpp:220-222).
+ */
+#ifndef RAYTRACER_AMD_H
+#define RAYTRACER_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------ */
+enum {
+   RT_OK = 0,
+   RT_ERR_BAD_ARGUMENT = 1,   /* null pointer, non-positive size, ...            */
+   RT_ERR_BAD_SAMPLE_COUNT = 2, /* sampleCount is not a perfect square (kernel.cu:707-712) */
+   RT_ERR_NO_DEVICE = 3,      /* no HIP device / HIP runtime failure at init      */
+   RT_ERR_HIP = 4,            /* a HIP call failed; rt_last_error() has the text  */
+   RT_ERR_UNSUPPORTED = 5,    /* textured pigment (image_map) -- out of scope     */
+   RT_ERR_PARSE = 6,          /* scene file missing or malformed                  */
+   RT_ERR_IO = 7,
+   RT_ERR_NO_CAMERA = 8,      /* the reference dereferences data->camera unchecked (kernel.cu:716) */
+   RT_ERR_TOO_LARGE = 9
+};
+
+/* ShadingType of kernel.h:22 */
+enum { RT_PHONG = 0, RT_COOK_TORRANCE = 1 };
+
+/* How the two uniform draws of generateCameraRays (kernel.cu:488-489) are made.
+ * The reference draws them from cuRAND XORWOW states, which cannot be
+ * reproduced without cuRAND; RT_JITTER_HASH is this library's own
+ * counter-based generator (a 32-bit integer hash of the sample index and seed), RT_JITTER_NONE pins both
+ * draws to 0.5 so that the sample sits in the centre of its stratum. */
+enum { RT_JITTER_NONE = 0, RT_JITTER_HASH = 1 };
+
+/* Output layouts of rt_render_device */
+enum {
+   RT_OUT_FRAME = 0,   /* full W*H frame, row-major; only this call's tiles are written */
+   RT_OUT_TILES = 1    /* compact: this call's tiles back to back, each RT_TILE x RT_TILE pixels row-major */
+};
+
+#define RT_TILE 32          /* pixels per tile edge (tiles are the multi-GPU sharding unit) */
+#define RT_MAX_RECURSE 6    /* kMaxRecurse, kernel.h:23 */
+
+/* ---- scene description (host, POD) ------------------------------------- */
+
+/* Material.h:8-20 (field order follows the Material constructor call sites,
+ * kernel.cu:414-450): pigment colour, pigment filter, finish terms. */
+typedef struct rt_material {
+   float clr[3];
+   float alpha;      /* pigment filter (rgbf 4th component) */
+   float amb, dif, spec, rough, refl, refr, ior;
+   int32_t tex_id;   /* -1 = untextured; anything else is RT_ERR_UNSUPPORTED */
+} rt_material;
+
+/* TKModifier (TokenData.h:46-51) with pigment+finish folded into rt_material. */
+typedef struct rt_modifier {
+   rt_material mat;
+   float trans[16];      /* object -> world */
+   float inv_trans[16];  /* world -> object */
+} rt_modifier;
+
+typedef struct rt_sphere   { float c[3]; float r; rt_modifier mod; } rt_sphere;              /* TKSphere   TokenData.h:65-69 */
+typedef struct rt_triangle { float p1[3], p2[3], p3[3]; rt_modifier mod; } rt_triangle;     /* TKTriangle TokenData.h:83-87 (UVs dropped) */
+typedef struct rt_box      { float p1[3], p2[3]; rt_modifier mod; } rt_box;                 /* TKBox      TokenData.h:60-63 */
+typedef struct rt_smooth_triangle {                                                         /* TKSmoothTriangle TokenData.h:89-94 */
+   float p1[3], p2[3], p3[3];
+   float n1[3], n2[3], n3[3];
+   rt_modifier mod;
+} rt_smooth_triangle;
+typedef struct rt_plane    { float n[3]; float d; rt_modifier mod; } rt_plane;              /* TKPlane    TokenData.h:71-75 */
+typedef struct rt_light    { float pos[3]; float clr[3]; } rt_light;                        /* TKPointLight TokenData.h:53-58 */
+typedef struct rt_camera   { float pos[3], up[3], right[3], look_at[3]; } rt_camera;        /* TKCamera   TokenData.h:11-17 */
+
+typedef struct rt_scene_desc {
+   rt_camera camera;
+   int32_t has_camera;
+   int32_t n_spheres;          const rt_sphere *spheres;
+   int32_t n_triangles;        const rt_triangle *triangles;
+   int32_t n_boxes;            const rt_box *boxes;
+   int32_t n_smooth_triangles; const rt_smooth_triangle *smooth_triangles;
+   int32_t n_planes;           const rt_plane *planes;
+   int32_t n_lights;           const rt_light *lights;
+} rt_scene_desc;
+
+/* ---- render parameters / statistics ------------------------------------ */
+typedef struct rt_render_params {
+   int32_t width, height;
+   int32_t sample_count;   /* must be a perfect square; s = sqrt(sample_count) strata per pixel edge */
+   int32_t shading;        /* RT_PHONG / RT_COOK_TORRANCE */
+   int32_t jitter;         /* RT_JITTER_* */
+   uint32_t seed;          /* RT_JITTER_HASH seed */
+   int32_t max_recurse;    /* 1..RT_MAX_RECURSE; 0 means RT_MAX_RECURSE */
+   /* image-tile sharding: this call renders tiles tile_first, tile_first+tile_stride, ...
+    * (tile index = ty * tiles_x + tx, tiles_x = ceil(width/RT_TILE)).  0/0 or 0/1 = whole frame. */
+   int32_t tile_first, tile_stride;
+   int32_t out_layout;     /* RT_OUT_FRAME / RT_OUT_TILES */
+} rt_render_params;
+
+typedef struct rt_stats {
+   /* every closest-hit / any-hit query that was traversed, by kind */
+   uint64_t rays_primary, rays_shadow, rays_reflect, rays_refract;
+   uint64_t rays_total;
+   uint64_t shadow_skipped;     /* shadow feelers whose self-test missed: the reference still walks the tree for them, the outcome is always "lit" */
+   uint64_t shade_nodes;        /* shadeObject invocations */
+   uint64_t samples;
+   /* device time, ms (HIP events on the render stream) */
+   float ms_total;              /* first extend launch -> resolve completion */
+   float ms_extend, ms_shadow, ms_shade, ms_combine, ms_resolve;
+   int32_t launches_extend, launches_shadow;
+   /* traversal work counters (only filled when the scene was created with RT_SCENE_COUNTERS) */
+   uint64_t node_visits, prim_tests, tie_events;
+} rt_stats;
+
+typedef struct rt_scene_info {
+   int32_t n_bvh_prims, n_planes, n_lights, n_nodes, n_materials;
+   int32_t tree_depth;       /* edges on the longest root->leaf path */
+   int32_t root;             /* node index, or ~prim when the tree is a single leaf, or INT32_MIN when empty */
+   uint64_t device_bytes;
+   float ms_build_host, ms_upload;
+} rt_scene_info;
+
+/* Flattened BVH node, 64 bytes: both children's boxes live in the parent so
+ * one aligned fetch serves both slab tests.  child >= 0: internal node index;
+ * child < 0: leaf, primitive id = ~child.  Topology and boxes are those of
+ * formBVH (bvh.cpp:30-223) -- see rt_scene_create. */
+typedef struct rt_bvh_node {
+   float lmin[3], lmax[3];
+   float rmin[3], rmax[3];
+   int32_t left, right;
+   int32_t pad[2];
+} rt_bvh_node;
+
+typedef struct rt_scene rt_scene;   /* opaque: host copy + device-resident flat scene */
+
+/* scene creation flags */
+enum { RT_SCENE_DEFAULT = 0, RT_SCENE_COUNTERS = 1 };
+
+/* ---- entry points ------------------------------------------------------ */
+
+/* Number of HIP devices visible, or 0.  Never fails. */
+int rt_device_count(void);
+
+/* Text of the last error on the calling thread ("" if none). */
+const char *rt_last_error(void);
+
+/* Build the device scene for `device`: objects in the reference's creation
+ * order (initScene, kernel.cu:384-464), the reference's BVH topology and
+ * boxes (formBVH, bvh.cpp:30-103, built here on the host), flattened into
+ * 64-byte records and uploaded.  Replaces allocateGPUScene + formBVH
+ * (kernel.cu:572-687, 732-733). */
+int rt_scene_create(const rt_scene_desc *desc, int device, int flags, rt_scene **out);
+void rt_scene_destroy(rt_scene *scene);
+int rt_scene_get_info(const rt_scene *scene, rt_scene_info *info);
+
+/* Host-side views for tests: the flattened node array (n_nodes records) and
+ * the BVH leaf order (n_bvh_prims primitive ids, the sorted geomList of
+ * bvh.cpp:49-72).  The pointers stay valid until rt_scene_destroy. */
+int rt_scene_get_bvh(const rt_scene *scene, const rt_bvh_node **nodes, const int32_t **leaf_order);
+
+/* Replace the camera of an existing scene (no rebuild). */
+int rt_scene_set_camera(rt_scene *scene, const rt_camera *camera);
+
+/* Whole frame into a caller-owned HOST buffer of width*height*4 bytes:
+ * generate -> extend -> shadow -> shade (x depth) -> combine -> resolve -> D2H.
+ * This is the body of launch_kernel after scene set-up (kernel.cu:735-760).
+ * stats may be NULL. */
+int rt_render(const rt_scene *scene, const rt_render_params *params,
+              uint8_t *out_rgba_host, rt_stats *stats);
+
+/* Same, output left in DEVICE memory (`out_rgba_dev`, layout per
+ * params->out_layout), work enqueued on `stream` (a hipStream_t, may be NULL
+ * for the default stream).  Returns after the stream has been synchronised
+ * (the wavefront queue sizes are read back between depth levels).
+ * Bytes needed: RT_OUT_FRAME width*height*4; RT_OUT_TILES rt_tile_count()*RT_TILE*RT_TILE*4. */
+int rt_render_device(const rt_scene *scene, const rt_render_params *params,
+                     void *out_rgba_dev, void *stream, rt_stats *stats);
+
+/* Number of tiles a (first, stride) selection covers for a width x height frame. */
+int rt_tile_count(int width, int height, int tile_first, int tile_stride);
+
+/* Scatter `n_parts` compact tile buffers (RT_OUT_TILES, part p made with
+ * tile_first = p, tile_stride = n_parts), laid back to back in `tiles_dev`
+ * with `part_stride_bytes` between parts, into a row-major device frame. */
+int rt_untile_device(const void *tiles_dev, size_t part_stride_bytes, int n_parts,
+                     int width, int height, void *frame_dev, void *stream);
+
+/* Parity/debug views of the same kernels.
+ * Per-sample closest hit of the primary rays (the first getClosestIntersection
+ * of rayTrace, kernel.cu:531): prim_ids[i] (-1 = miss) and t[i] for sample
+ * i = y*(width*s) + x; both host arrays of width*s*height*s entries. */
+int rt_trace_primary(const rt_scene *scene, const rt_render_params *params,
+                     int32_t *prim_ids_host, float *t_host);
+
+/* Closest hit of arbitrary rays: rays_host = n x {ox,oy,oz,dx,dy,dz};
+ * to_beat_host may be NULL (= -FLT_MAX for every ray, kernel.cu:84). */
+int rt_trace_rays(const rt_scene *scene, int64_t n, const float *rays_host,
+                  const float *to_beat_host, int32_t *prim_ids_host, float *t_host);
+
+/* Per-sample clamped float RGB, the reference's antiAliasBuffer
+ * (kernel.cu:537-541): n_samples x 3 floats, host. */
+int rt_render_samples(const rt_scene *scene, const rt_render_params *params,
+                      float *rgb_host, rt_stats *stats);
+
+/* ---- host-side pieces either side of the path -------------------------- */
+
+/* POV-Ray-subset parser (POVRayParser::parseFile, POVRayParser.cpp:14-62).
+ * The returned description owns its arrays; free with rt_scene_desc_free. */
+int rt_parse_pov(const char *path, rt_scene_desc **out);
+void rt_scene_desc_free(rt_scene_desc *desc);
+
+/* 24-bit uncompressed TGA exactly as the reference's driver + Image::WriteTga
+ * produce it from the uchar4 frame (raytrace.cpp:44-55, Image.cpp:38-101). */
+int rt_write_tga(const char *path, int width, int height, const uint8_t *rgba);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACER_AMD_H */
