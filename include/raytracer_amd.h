@@ -175,6 +175,10 @@ const char *rt_last_error(void);
  * 64-byte records and uploaded.  Replaces allocateGPUScene + formBVH
  * (kernel.cu:572-687, 732-733). */
 int rt_scene_create(const rt_scene_desc *desc, int device, int flags, rt_scene **out);
+/* The host half of rt_scene_create alone (no device is touched): the returned
+ * scene answers rt_scene_get_info / rt_scene_get_bvh and nothing else; every
+ * render entry point rejects it with RT_ERR_NO_DEVICE. */
+int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out);
 void rt_scene_destroy(rt_scene *scene);
 int rt_scene_get_info(const rt_scene *scene, rt_scene_info *info);
 

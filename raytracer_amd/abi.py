@@ -95,7 +95,7 @@ class SceneInfo(C.Structure):
 
 # every symbol include/raytracer_amd.h and include/raytracer_tokens.h declare
 EXPORTED_SYMBOLS = [
-    "rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info",
+    "rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_create_host", "rt_scene_destroy", "rt_scene_get_info",
     "rt_scene_get_bvh", "rt_scene_set_camera", "rt_render", "rt_render_device", "rt_tile_count",
     "rt_untile_device", "rt_trace_primary", "rt_trace_rays", "rt_render_samples",
     "rt_parse_pov", "rt_scene_desc_free", "rt_write_tga", "launch_kernel",
@@ -119,6 +119,7 @@ def load_library(path=None):
     lib.rt_device_count.restype = C.c_int
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_int, C.POINTER(vp)]
+    lib.rt_scene_create_host.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
     lib.rt_scene_destroy.argtypes = [vp]
     lib.rt_scene_destroy.restype = None
     lib.rt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]

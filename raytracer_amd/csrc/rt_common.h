@@ -1,0 +1,89 @@
+/*
+ * rt_common.h -- records of the flat device scene, shared by the host builder
+ * (rt_scene_build.cpp) and the HIP kernels (rt_render.hip).
+ *
+ * Every record is a multiple of 16 bytes and the hot ones (BVH node, primitive
+ * intersection record) are exactly one 64-byte line, so a lane fetches a record
+ * with four 16-byte loads from one aligned line.
+ */
+#ifndef RT_COMMON_H
+#define RT_COMMON_H
+
+#include <stdint.h>
+#include "raytracer_amd.h"
+
+/* primitive classes, numbered in the reference's geomList order (kernel.cu:419-456) */
+enum { RT_PRIM_SPHERE = 0, RT_PRIM_TRIANGLE = 1, RT_PRIM_BOX = 2, RT_PRIM_SMOOTH = 3 };
+
+#define RT_FLAG_XFORM 1u      /* inv_trans is not the identity: the ray must be transformed (Geometry.h:16-18) */
+
+#define RT_ROOT_EMPTY INT32_MIN
+
+/* Intersection record.
+ *   sphere   g[0..2] centre, g[3] radius                          (Sphere.h:42-66)
+ *   triangle g[0..8] p1 p2 p3, g[9..11] normalised face normal    (Triangle.h:11-22, 55-103)
+ *   box      g[0..2] minP, g[3..5] maxP                           (Box.h:13-19, 37-39)          */
+typedef struct rt_dev_prim {
+   float g[12];
+   uint32_t type;
+   uint32_t flags;
+   uint32_t material;
+   uint32_t pad;
+} rt_dev_prim;
+
+/* Rows 0..2 of inv_trans (the 4th row never reaches the .xyz the reference keeps, Ray.h:8-12):
+ * r[k][c] = inv_trans[c][k], i.e. r[k] = {m[0][k], m[1][k], m[2][k], m[3][k]}. */
+typedef struct rt_dev_xform {
+   float r[3][4];
+} rt_dev_xform;
+
+/* Shading record: what getNormalAt needs beyond the intersection record.
+ *   sphere   s[0..2] world-space centre                           (Sphere.h:13-14, 19-24)
+ *   triangle s[0..2] world-space normal = (n,0) * inv_trans       (Triangle.h:20-26)
+ *   smooth   s[0..8] wsN1 wsN2 wsN3                               (SmoothTriangle.h:21-38)
+ *   box      s[0..8] columns 0..2 of trans, rows 0..2             (Box.h:59)                    */
+typedef struct rt_dev_shade {
+   float s[12];
+   uint32_t pad[4];
+} rt_dev_shade;
+
+/* Plane (not in the BVH; scanned linearly after it, kernel.cu:189-196). */
+typedef struct rt_dev_plane {
+   float n[3]; float d;          /* Plane.h:39-50 */
+   rt_dev_xform inv;
+   float wsN[3];                 /* Plane.h:15-16 */
+   uint32_t flags;
+   uint32_t material;
+   uint32_t pad[3];
+} rt_dev_plane;
+
+typedef struct rt_dev_light { float pos[3]; float pad0; float clr[3]; float pad1; } rt_dev_light;
+
+/* The host-side result of flattening a scene description. */
+typedef struct rt_flat_scene {
+   int32_t n_prims, n_planes, n_lights, n_nodes, n_materials;
+   int32_t root, tree_depth;
+   rt_bvh_node *nodes;         /* n_nodes */
+   rt_dev_prim *prims;         /* n_prims, indexed by primitive id */
+   rt_dev_xform *xforms;       /* n_prims */
+   rt_dev_shade *shades;       /* n_prims */
+   rt_dev_plane *planes;       /* n_planes */
+   rt_material *materials;     /* n_materials (deduplicated) */
+   rt_dev_light *lights;       /* n_lights */
+   int32_t *leaf_order;        /* n_prims: geomList after formBVH's sort rounds */
+   int32_t any_xform;
+} rt_flat_scene;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Host: objects in initScene order + reference-topology BVH + flattening.
+ * Returns RT_OK or an RT_ERR_* code; on success the arrays are malloc'ed. */
+int rt_flatten_scene(const rt_scene_desc *desc, rt_flat_scene *out);
+void rt_flat_scene_free(rt_flat_scene *fs);
+void rt_set_error(const char *fmt, ...);
+#ifdef __cplusplus
+}
+#endif
+
+#endif

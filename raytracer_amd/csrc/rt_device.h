@@ -1,0 +1,198 @@
+/*
+ * rt_device.h -- device-side arithmetic of the render path (gfx950, wave64).
+ *
+ * Everything here is IEEE binary32 with the operation order of the reference
+ * (GLM 0.9.3 semantics: dot and cross left to right, normalize = v * (1/sqrt),
+ * mat*vec row sums left to right) and must be compiled with -ffp-contract=off:
+ * which primitive a ray reports depends on comparisons of these values, so a
+ * fused multiply-add in the wrong place changes hit ids.  The only fused
+ * operations are the explicit __builtin_fmaf calls in rt_div(), which are an
+ * exact-division algorithm, not a contraction.
+ */
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "rt_common.h"
+
+#define RT_EPS 0.0001f          /* EPSILON, Util.h:4 */
+#define RT_BIG_EPS 0.001f       /* BIG_EPSILON, Util.h:5 */
+#define RT_EQ_EPS 0.01f         /* EQUAL_EPSILON, Util.h:6 */
+#define RT_AIR_IOR 1.0f         /* kAirIOR, kernel.h:24 */
+
+struct F3 { float x, y, z; };
+
+__device__ __forceinline__ F3 mk3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ F3 operator*(float s, F3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ F3 operator-(F3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 cross3(F3 x, F3 y)
+{
+   return mk3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+__device__ __forceinline__ F3 normalize3(F3 v)
+{
+   float sqr = v.x * v.x + v.y * v.y + v.z * v.z;
+   float inv = 1.0f / sqrtf(sqr);     /* correctly rounded sqrt and divide (hipcc default) */
+   return mk3(v.x * inv, v.y * inv, v.z * inv);
+}
+
+/* Util.h:8-42 */
+__device__ __forceinline__ bool is_zero(float n) { return n < RT_EPS && n > -RT_EPS; }
+__device__ __forceinline__ bool is_equal(float a, float b) { return a + RT_EQ_EPS > b && b + RT_EQ_EPS > a; }
+__device__ __forceinline__ bool above_zero(float n) { return n + RT_EPS > 0.0f; }
+__device__ __forceinline__ bool less_than(float l, float r) { return l + RT_EPS < r; }
+__device__ __forceinline__ float clamp01(float x) { return x > 1.0f ? 1.0f : x < 0.0f ? 0.0f : x; }
+__device__ __forceinline__ float my_min(float x, float y) { return x < y ? x : y; }
+__device__ __forceinline__ float my_max(float x, float y) { return x > y ? x : y; }
+
+struct Ray { F3 o, d; };
+__device__ __forceinline__ F3 ray_point(const Ray &r, float t) { return r.o + r.d * t; }   /* Ray.h:7 */
+
+/* Ray::transform (Ray.h:8-12) with the three kept rows of inv_trans.
+ * Origin: m0*x + m1*y + m2*z + m3*1; direction: ... + m3*0. */
+__device__ __forceinline__ Ray ray_transform(const Ray &r, const rt_dev_xform &m)
+{
+   Ray o;
+   o.o.x = m.r[0][0] * r.o.x + m.r[0][1] * r.o.y + m.r[0][2] * r.o.z + m.r[0][3] * 1.0f;
+   o.o.y = m.r[1][0] * r.o.x + m.r[1][1] * r.o.y + m.r[1][2] * r.o.z + m.r[1][3] * 1.0f;
+   o.o.z = m.r[2][0] * r.o.x + m.r[2][1] * r.o.y + m.r[2][2] * r.o.z + m.r[2][3] * 1.0f;
+   o.d.x = m.r[0][0] * r.d.x + m.r[0][1] * r.d.y + m.r[0][2] * r.d.z + m.r[0][3] * 0.0f;
+   o.d.y = m.r[1][0] * r.d.x + m.r[1][1] * r.d.y + m.r[1][2] * r.d.z + m.r[1][3] * 0.0f;
+   o.d.z = m.r[2][0] * r.d.x + m.r[2][1] * r.d.y + m.r[2][2] * r.d.z + m.r[2][3] * 0.0f;
+   return o;
+}
+
+/* ---- exact division by a per-ray constant -------------------------------
+ * The slab test divides (bound - origin) by the ray direction six times per
+ * box (GeometryUtil.h:17-32) and the quotients are compared with each other
+ * and with t, so they must be the correctly rounded a/d.  hipcc's own a/d is
+ * ~10 instructions; with y = RN(1/d) computed once per ray (a true division)
+ * two residual corrections give RN(a/d) in 5 (Markstein: q' = q + (a - d*q)*y
+ * is correctly rounded once q is within an ulp and y = RN(1/d)).
+ * Valid while a, d, the quotient and the residuals stay normal; rays whose
+ * origin or direction is outside [2^-60, 2^60] take the plain a/d path. */
+template <bool FAST>
+__device__ __forceinline__ float rt_div(float a, float d, float y)
+{
+   if (FAST) {
+      float q0 = a * y;
+      float r0 = __builtin_fmaf(-d, q0, a);
+      float q1 = __builtin_fmaf(r0, y, q0);
+      float r1 = __builtin_fmaf(-d, q1, a);
+      return __builtin_fmaf(r1, y, q1);
+   } else {
+      return a / d;
+   }
+}
+
+__device__ __forceinline__ bool in_div_range(float v)
+{
+   float a = fabsf(v);
+   return a == 0.0f || (a >= 8.673617379884035e-19f && a <= 1.152921504606847e18f);   /* 2^-60 .. 2^60 */
+}
+
+/* per-ray constants of the slab test */
+struct RayCtx {
+   Ray r;
+   float yx, yy, yz;      /* RN(1/d) per axis (unused where the axis is parallel) */
+   bool px, py, pz;       /* isFloatZero(d.axis), GeometryUtil.h:16,23,30 */
+   bool fast;             /* all values inside rt_div's safe range */
+};
+
+__device__ __forceinline__ RayCtx make_ctx(const Ray &r)
+{
+   RayCtx c;
+   c.r = r;
+   c.px = is_zero(r.d.x); c.py = is_zero(r.d.y); c.pz = is_zero(r.d.z);
+   c.yx = 1.0f / r.d.x; c.yy = 1.0f / r.d.y; c.yz = 1.0f / r.d.z;
+   c.fast = in_div_range(r.o.x) && in_div_range(r.o.y) && in_div_range(r.o.z) &&
+            (c.px || in_div_range(r.d.x)) && (c.py || in_div_range(r.d.y)) && (c.pz || in_div_range(r.d.z));
+   return c;
+}
+
+/* boxIntersect, GeometryUtil.h:9-51 */
+template <bool FAST>
+__device__ __forceinline__ float slab_test(const RayCtx &c, float mnx, float mny, float mnz,
+                                           float mxx, float mxy, float mxz)
+{
+   const Ray &r = c.r;
+   bool miss = false;
+   float tXmin = -FLT_MAX, tYmin = -FLT_MAX, tZmin = -FLT_MAX;
+   float tXmax = FLT_MAX, tYmax = FLT_MAX, tZmax = FLT_MAX;
+   if (!c.px) {
+      tXmin = rt_div<FAST>(mnx - r.o.x, r.d.x, c.yx);
+      tXmax = rt_div<FAST>(mxx - r.o.x, r.d.x, c.yx);
+   } else if (r.o.x < mnx || r.o.x > mxx) miss = true;
+   if (!c.py) {
+      tYmin = rt_div<FAST>(mny - r.o.y, r.d.y, c.yy);
+      tYmax = rt_div<FAST>(mxy - r.o.y, r.d.y, c.yy);
+   } else if (r.o.y < mny || r.o.y > mxy) miss = true;
+   if (!c.pz) {
+      tZmin = rt_div<FAST>(mnz - r.o.z, r.d.z, c.yz);
+      tZmax = rt_div<FAST>(mxz - r.o.z, r.d.z, c.yz);
+   } else if (r.o.z < mnz || r.o.z > mxz) miss = true;
+
+   float xl = tXmin > tXmax ? tXmax : tXmin, xh = tXmin > tXmax ? tXmin : tXmax;
+   float yl = tYmin > tYmax ? tYmax : tYmin, yh = tYmin > tYmax ? tYmin : tYmax;
+   float zl = tZmin > tZmax ? tZmax : tZmin, zh = tZmin > tZmax ? tZmin : tZmax;
+   float tBiggestMin = my_max(my_max(xl, yl), zl);
+   float tSmallestMax = my_min(my_min(xh, yh), zh);
+   bool inside = r.o.x > mnx && r.o.x < mxx && r.o.y > mny && r.o.y < mxy && r.o.z > mnz && r.o.z < mxz;
+   float res = inside ? tSmallestMax : (tBiggestMin < tSmallestMax ? tBiggestMin : -1.0f);
+   return miss ? -1.0f : res;
+}
+
+/* Sphere::intersects, Sphere.h:42-66 (ray already in object space) */
+__device__ __forceinline__ float sphere_hit(const Ray &ray, F3 c, float rad)
+{
+   F3 e = ray.o - c;
+   float dDotD = dot3(ray.d, ray.d);
+   float de = dot3(ray.d, e);
+   float disc = de * de - dDotD * (dot3(e, e) - rad * rad);
+   if (disc < 0.0f) return -1.0f;
+   float nde = dot3(-ray.d, e);
+   float sq = sqrtf(disc);
+   float first = (nde - sq) / dDotD;
+   if (less_than(0.0f, first)) return first;
+   return (nde + sq) / dDotD;
+}
+
+/* Plane::intersects, Plane.h:39-50 */
+__device__ __forceinline__ float plane_hit(const Ray &r, F3 n, float d)
+{
+   F3 c = n * d;
+   float numer = dot3(-n, r.o - c);
+   float denom = dot3(n, r.d);
+   if (is_zero(numer) || is_zero(denom)) return -1.0f;
+   float t = numer / denom;
+   if (less_than(t, 0.0f)) return -1.0f;
+   return t;
+}
+
+/* Triangle::intersects, Triangle.h:55-103 */
+__device__ __forceinline__ float triangle_hit(const Ray &r, F3 A, F3 B, F3 C, F3 n)
+{
+   float numer = dot3(-n, r.o - A);
+   float denom = dot3(n, r.d);
+   if (is_zero(numer) || is_zero(denom)) return -1.0f;
+   float t = numer / denom;
+   if (less_than(t, 0.0f)) return -1.0f;
+   F3 P = ray_point(r, t);
+   F3 AB = B - A, AC = C - A;
+   F3 N = cross3(AB, AC);
+   F3 AP = P - A;
+   if (dot3(N, cross3(AB, AP)) < 0.0f) return -1.0f;
+   F3 BP = P - B, BC = C - B;
+   if (dot3(N, cross3(BC, BP)) < 0.0f) return -1.0f;
+   F3 CP = P - C;
+   if (dot3(N, cross3(CP, AC)) < 0.0f) return -1.0f;
+   return t;
+}
+
+#endif

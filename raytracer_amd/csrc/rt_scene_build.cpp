@@ -1,0 +1,431 @@
+/*
+ * rt_scene_build.cpp -- host side of scene set-up: turns a scene description
+ * into the flat device records of rt_common.h.
+ *
+ * Replaces, on the host, what the reference does with device-side `new` and a
+ * GPU merge sort: initScene (kernel.cu:384-464) and formBVH (bvh.cpp:30-223).
+ * The resulting TREE IS THE REFERENCE'S TREE -- same leaf order, same pairing,
+ * same boxes bit for bit -- because which primitive wins a near-tie depends on
+ * the order the traversal meets them (kernel.cu:108-134).
+ *
+ * Arithmetic follows GLM 0.9.3's operation order (mat4*vec4 and vec4*mat4:
+ * glm/core/type_mat4x4.inl:689-714; cross/normalize: func_geometric.inl:199-248)
+ * in IEEE binary32 without contraction.
+ */
+#include "rt_common.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+const float kEps = 0.0001f;   /* EPSILON, Util.h:4 */
+
+struct F3 { float x, y, z; };
+inline F3 f3(const float *p) { return F3{p[0], p[1], p[2]}; }
+inline F3 operator-(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline F3 operator+(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline F3 cross(F3 x, F3 y) { return F3{x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
+inline F3 normalize(F3 v)
+{
+   float sqr = v.x * v.x + v.y * v.y + v.z * v.z;
+   float inv = 1.0f / std::sqrt(sqr);
+   return F3{v.x * inv, v.y * inv, v.z * inv};
+}
+inline float lo(float a, float b) { return a < b ? a : b; }   /* mymin, Util.h:36-38 */
+inline float hi(float a, float b) { return a > b ? a : b; }   /* mymax, Util.h:40-42 */
+
+/* M * (x,y,z,w), column-major M; only .xyz is ever kept by the callers */
+inline F3 mat_vec(const float *m, float x, float y, float z, float w)
+{
+   return F3{m[0] * x + m[4] * y + m[8] * z + m[12] * w,
+             m[1] * x + m[5] * y + m[9] * z + m[13] * w,
+             m[2] * x + m[6] * y + m[10] * z + m[14] * w};
+}
+/* (x,y,z,w) * M: component c is the dot with column c */
+inline F3 vec_mat(float x, float y, float z, float w, const float *m)
+{
+   return F3{m[0] * x + m[1] * y + m[2] * z + m[3] * w,
+             m[4] * x + m[5] * y + m[6] * z + m[7] * w,
+             m[8] * x + m[9] * y + m[10] * z + m[11] * w};
+}
+
+struct Box3 { F3 mn, mx; };
+/* every BoundingBox construction pads by EPSILON (BoundingBox.h:11-15) */
+inline Box3 padded(F3 mn, F3 mx)
+{
+   return Box3{F3{mn.x - kEps, mn.y - kEps, mn.z - kEps}, F3{mx.x + kEps, mx.y + kEps, mx.z + kEps}};
+}
+/* generateBoundingBox, BoundingBox.h:24-46 */
+Box3 corners_box(F3 mn, F3 mx, const float *trans)
+{
+   float lo3[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi3[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+   for (int i = 0; i < 8; i++) {
+      F3 p = mat_vec(trans, (i & 1) ? mx.x : mn.x, (i & 2) ? mx.y : mn.y, (i & 4) ? mx.z : mn.z, 1.0f);
+      float q[3] = {p.x, p.y, p.z};
+      for (int a = 0; a < 3; a++) {
+         if (q[a] < lo3[a]) lo3[a] = q[a];
+         if (q[a] > hi3[a]) hi3[a] = q[a];
+      }
+   }
+   return padded(f3(lo3), f3(hi3));
+}
+/* combineBoundingBox, BoundingBox.h:48-52 */
+inline Box3 merged(const Box3 &a, const Box3 &b)
+{
+   return padded(F3{lo(a.mn.x, b.mn.x), lo(a.mn.y, b.mn.y), lo(a.mn.z, b.mn.z)},
+                 F3{hi(a.mx.x, b.mx.x), hi(a.mx.y, b.mx.y), hi(a.mx.z, b.mx.z)});
+}
+
+bool is_identity(const float *m)
+{
+   for (int c = 0; c < 4; c++)
+      for (int r = 0; r < 4; r++)
+         if (m[c * 4 + r] != (c == r ? 1.0f : 0.0f)) return false;
+   return true;
+}
+
+void put(float *dst, F3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
+
+void fill_xform(rt_dev_xform *x, const float *inv)
+{
+   for (int k = 0; k < 3; k++)
+      for (int c = 0; c < 4; c++) x->r[k][c] = inv[c * 4 + k];
+}
+
+struct MatKey {
+   rt_material m;
+   bool operator<(const MatKey &o) const { return memcmp(&m, &o.m, sizeof m) < 0; }
+};
+
+struct Builder {
+   std::vector<rt_dev_prim> prims;
+   std::vector<rt_dev_xform> xforms;
+   std::vector<rt_dev_shade> shades;
+   std::vector<Box3> boxes;       /* getBoundingBox() per primitive */
+   std::vector<F3> centers;       /* getCenter() per primitive: the sort key */
+   std::vector<rt_material> materials;
+   std::map<MatKey, uint32_t> mat_index;
+   int any_xform = 0;
+
+   uint32_t material(const rt_material &m)
+   {
+      MatKey k; memset(&k, 0, sizeof k); k.m = m;
+      auto it = mat_index.find(k);
+      if (it != mat_index.end()) return it->second;
+      uint32_t id = (uint32_t)materials.size();
+      materials.push_back(m);
+      mat_index[k] = id;
+      return id;
+   }
+
+   void common(rt_dev_prim &p, uint32_t type, const rt_modifier &mod)
+   {
+      memset(&p, 0, sizeof p);
+      p.type = type;
+      p.material = material(mod.mat);
+      if (!is_identity(mod.inv_trans)) { p.flags |= RT_FLAG_XFORM; any_xform = 1; }
+      rt_dev_xform x; fill_xform(&x, mod.inv_trans);
+      xforms.push_back(x);
+   }
+
+   /* Sphere.h:10-15, 26-32 */
+   void add_sphere(const rt_sphere &s)
+   {
+      rt_dev_prim p; common(p, RT_PRIM_SPHERE, s.mod);
+      p.g[0] = s.c[0]; p.g[1] = s.c[1]; p.g[2] = s.c[2]; p.g[3] = s.r;
+      rt_dev_shade sh; memset(&sh, 0, sizeof sh);
+      F3 wc = mat_vec(s.mod.trans, s.c[0], s.c[1], s.c[2], 1.0f);
+      put(sh.s, wc);
+      prims.push_back(p); shades.push_back(sh);
+      centers.push_back(wc);
+      boxes.push_back(corners_box(F3{s.c[0] - s.r, s.c[1] - s.r, s.c[2] - s.r},
+                                  F3{s.c[0] + s.r, s.c[1] + s.r, s.c[2] + s.r}, s.mod.trans));
+   }
+
+   /* Triangle.h:11-42; SmoothTriangle.h:12-28 */
+   void add_triangle(const float *a, const float *b, const float *c, const rt_modifier &mod,
+                     const float *n1, const float *n2, const float *n3)
+   {
+      rt_dev_prim p; common(p, n1 ? RT_PRIM_SMOOTH : RT_PRIM_TRIANGLE, mod);
+      F3 p1 = f3(a), p2 = f3(b), p3 = f3(c);
+      F3 n = normalize(cross(p2 - p1, p3 - p1));
+      put(&p.g[0], p1); put(&p.g[3], p2); put(&p.g[6], p3); put(&p.g[9], n);
+      rt_dev_shade sh; memset(&sh, 0, sizeof sh);
+      if (n1) {
+         put(&sh.s[0], vec_mat(n1[0], n1[1], n1[2], 0.0f, mod.inv_trans));
+         put(&sh.s[3], vec_mat(n2[0], n2[1], n2[2], 0.0f, mod.inv_trans));
+         put(&sh.s[6], vec_mat(n3[0], n3[1], n3[2], 0.0f, mod.inv_trans));
+      } else {
+         put(&sh.s[0], vec_mat(n.x, n.y, n.z, 0.0f, mod.inv_trans));
+      }
+      prims.push_back(p); shades.push_back(sh);
+      /* sort key: centroid as a ROW vector times trans -- the translation column never enters (Triangle.h:28-31) */
+      F3 s3 = (p1 + p2) + p3;
+      F3 cen = F3{s3.x / 3.0f, s3.y / 3.0f, s3.z / 3.0f};
+      centers.push_back(vec_mat(cen.x, cen.y, cen.z, 1.0f, mod.trans));
+      F3 t1 = mat_vec(mod.trans, p1.x, p1.y, p1.z, 1.0f);
+      F3 t2 = mat_vec(mod.trans, p2.x, p2.y, p2.z, 1.0f);
+      F3 t3 = mat_vec(mod.trans, p3.x, p3.y, p3.z, 1.0f);
+      F3 mn = F3{lo(lo(t1.x, t2.x), t3.x), lo(lo(t1.y, t2.y), t3.y), lo(lo(t1.z, t2.z), t3.z)};
+      F3 mx = F3{hi(hi(t1.x, t2.x), t3.x), hi(hi(t1.y, t2.y), t3.y), hi(hi(t1.z, t2.z), t3.z)};
+      boxes.push_back(padded(mn, mx));
+   }
+
+   /* Box.h:13-34 */
+   void add_box(const rt_box &b)
+   {
+      rt_dev_prim p; common(p, RT_PRIM_BOX, b.mod);
+      F3 mn = F3{lo(b.p1[0], b.p2[0]), lo(b.p1[1], b.p2[1]), lo(b.p1[2], b.p2[2])};
+      F3 mx = F3{hi(b.p1[0], b.p2[0]), hi(b.p1[1], b.p2[1]), hi(b.p1[2], b.p2[2])};
+      put(&p.g[0], mn); put(&p.g[3], mx);
+      rt_dev_shade sh; memset(&sh, 0, sizeof sh);
+      for (int c = 0; c < 3; c++)
+         for (int r = 0; r < 3; r++) sh.s[c * 3 + r] = b.mod.trans[c * 4 + r];
+      prims.push_back(p); shades.push_back(sh);
+      F3 s2 = mn + mx;
+      F3 mid = F3{s2.x / 2.0f, s2.y / 2.0f, s2.z / 2.0f};
+      centers.push_back(mat_vec(b.mod.trans, mid.x, mid.y, mid.z, 1.0f));
+      boxes.push_back(corners_box(mn, mx, b.mod.trans));
+   }
+};
+
+inline float axis_of(const F3 &v, int axis) { return axis == 0 ? v.x : axis == 1 ? v.y : v.z; }
+
+/* One sort round of formBVH: every queued range is sorted on `axis` by the
+ * bottom-up merge of bvh.cpp:106-171.  In a merge the LEFT run's head is taken
+ * only when its key is strictly smaller, so equal keys come out right-run
+ * first -- this is not std::stable_sort and must not be replaced by it. */
+void merge_sort_range(int32_t *ids, int32_t *tmp, int n, const std::vector<F3> &centers, int axis)
+{
+   int32_t *src = ids, *dst = tmp;
+   for (int width = 1; width < n; width *= 2) {
+      for (int base = 0; base < n; base += 2 * width) {
+         int i1 = base, i2 = base + width;
+         int e1 = i2 < n ? i2 : n;
+         int e2 = (i2 + width) < n ? (i2 + width) : n;
+         for (int i = base; i < e2; i++) {
+            if (i1 < e1 && (i2 >= e2 || axis_of(centers[src[i1]], axis) < axis_of(centers[src[i2]], axis)))
+               dst[i] = src[i1++];
+            else
+               dst[i] = src[i2++];
+         }
+      }
+      int32_t *t = src; src = dst; dst = t;
+   }
+   if (src != ids) memcpy(ids, src, sizeof(int32_t) * (size_t)n);
+}
+
+struct TreeNode {      /* BVHNode, bvh.h:10-19 */
+   int left, right;    /* indices into the TreeNode pool */
+   int prim;           /* >= 0: leaf */
+   Box3 bb;
+};
+
+/* Pre-order numbering (a parent is directly followed by its left subtree, so the
+ * first child visited is often in the next line), with an explicit stack:
+ * first number the internal nodes, then fill the records. */
+void flatten_tree(const std::vector<TreeNode> &pool, int root, std::vector<rt_bvh_node> &out, int *depth_out)
+{
+   std::vector<int32_t> index(pool.size(), -1);
+   std::vector<std::pair<int, int> > stack;   /* node, level */
+   int32_t next = 0;
+   int depth = 0;
+   stack.push_back(std::make_pair(root, 1));
+   std::vector<int> order;
+   while (!stack.empty()) {
+      std::pair<int, int> it = stack.back(); stack.pop_back();
+      const TreeNode &n = pool[it.first];
+      index[it.first] = next++;
+      order.push_back(it.first);
+      if (it.second > depth) depth = it.second;
+      if (pool[n.right].prim < 0) stack.push_back(std::make_pair(n.right, it.second + 1));
+      if (pool[n.left].prim < 0) stack.push_back(std::make_pair(n.left, it.second + 1));
+   }
+   out.resize((size_t)next);
+   for (size_t k = 0; k < order.size(); k++) {
+      const TreeNode &n = pool[order[k]];
+      const TreeNode &l = pool[n.left];
+      const TreeNode &r = pool[n.right];
+      rt_bvh_node rec; memset(&rec, 0, sizeof rec);
+      put(rec.lmin, l.bb.mn); put(rec.lmax, l.bb.mx);
+      put(rec.rmin, r.bb.mn); put(rec.rmax, r.bb.mx);
+      rec.left = l.prim >= 0 ? ~l.prim : index[n.left];
+      rec.right = r.prim >= 0 ? ~r.prim : index[n.right];
+      out[(size_t)index[order[k]]] = rec;
+   }
+   *depth_out = depth;
+}
+
+template <class T> T *copy_out(const std::vector<T> &v)
+{
+   T *p = (T *)malloc(sizeof(T) * (v.size() ? v.size() : 1));
+   if (!v.empty()) memcpy(p, v.data(), sizeof(T) * v.size());
+   return p;
+}
+
+} // namespace
+
+static thread_local char g_error[512];
+
+extern "C" void rt_set_error(const char *fmt, ...)
+{
+   va_list ap;
+   va_start(ap, fmt);
+   vsnprintf(g_error, sizeof g_error, fmt, ap);
+   va_end(ap);
+}
+extern "C" const char *rt_last_error(void) { return g_error; }
+
+extern "C" int rt_flatten_scene(const rt_scene_desc *d, rt_flat_scene *out)
+{
+   if (!d || !out) { rt_set_error("rt_flatten_scene: null argument"); return RT_ERR_BAD_ARGUMENT; }
+   if (d->n_spheres < 0 || d->n_triangles < 0 || d->n_boxes < 0 || d->n_smooth_triangles < 0 ||
+       d->n_planes < 0 || d->n_lights < 0) { rt_set_error("negative primitive count"); return RT_ERR_BAD_ARGUMENT; }
+   if ((d->n_spheres && !d->spheres) || (d->n_triangles && !d->triangles) || (d->n_boxes && !d->boxes) ||
+       (d->n_smooth_triangles && !d->smooth_triangles) || (d->n_planes && !d->planes) || (d->n_lights && !d->lights)) {
+      rt_set_error("primitive count without array"); return RT_ERR_BAD_ARGUMENT;
+   }
+   long long total = (long long)d->n_spheres + d->n_triangles + d->n_boxes + d->n_smooth_triangles;
+   if (total > 0x3fffffffLL) { rt_set_error("too many primitives"); return RT_ERR_TOO_LARGE; }
+   memset(out, 0, sizeof *out);
+
+   Builder b;
+   b.prims.reserve((size_t)total); b.xforms.reserve((size_t)total); b.shades.reserve((size_t)total);
+   b.boxes.reserve((size_t)total); b.centers.reserve((size_t)total);
+
+   /* planes first, as initScene does (kernel.cu:411-416); they stay out of the tree */
+   std::vector<rt_dev_plane> planes((size_t)d->n_planes);
+   for (int i = 0; i < d->n_planes; i++) {
+      const rt_plane &p = d->planes[i];
+      if (p.mod.mat.tex_id != -1) { rt_set_error("plane %d: textured pigments are not supported", i); return RT_ERR_UNSUPPORTED; }
+      rt_dev_plane &o = planes[(size_t)i];
+      memset(&o, 0, sizeof o);
+      o.n[0] = p.n[0]; o.n[1] = p.n[1]; o.n[2] = p.n[2]; o.d = p.d;
+      fill_xform(&o.inv, p.mod.inv_trans);
+      put(o.wsN, mat_vec(p.mod.trans, p.n[0], p.n[1], p.n[2], 0.0f));
+      if (!is_identity(p.mod.inv_trans)) o.flags |= RT_FLAG_XFORM;
+      o.material = b.material(p.mod.mat);
+   }
+   /* geomList order: spheres, triangles, boxes, smooth triangles (kernel.cu:419-456) */
+   for (int i = 0; i < d->n_spheres; i++) {
+      if (d->spheres[i].mod.mat.tex_id != -1) { rt_set_error("sphere %d: textured pigments are not supported", i); return RT_ERR_UNSUPPORTED; }
+      b.add_sphere(d->spheres[i]);
+   }
+   for (int i = 0; i < d->n_triangles; i++) {
+      const rt_triangle &t = d->triangles[i];
+      if (t.mod.mat.tex_id != -1) { rt_set_error("triangle %d: textured pigments are not supported", i); return RT_ERR_UNSUPPORTED; }
+      b.add_triangle(t.p1, t.p2, t.p3, t.mod, NULL, NULL, NULL);
+   }
+   for (int i = 0; i < d->n_boxes; i++) {
+      if (d->boxes[i].mod.mat.tex_id != -1) { rt_set_error("box %d: textured pigments are not supported", i); return RT_ERR_UNSUPPORTED; }
+      b.add_box(d->boxes[i]);
+   }
+   for (int i = 0; i < d->n_smooth_triangles; i++) {
+      const rt_smooth_triangle &t = d->smooth_triangles[i];
+      if (t.mod.mat.tex_id != -1) { rt_set_error("smooth_triangle %d: textured pigments are not supported", i); return RT_ERR_UNSUPPORTED; }
+      b.add_triangle(t.p1, t.p2, t.p3, t.mod, t.n1, t.n2, t.n3);
+   }
+
+   int n = (int)total;
+   std::vector<int32_t> order((size_t)(n > 0 ? n : 1)), tmp((size_t)(n > 0 ? n : 1));
+   for (int i = 0; i < n; i++) order[(size_t)i] = i;
+
+   std::vector<rt_bvh_node> flat;
+   int32_t root = RT_ROOT_EMPTY;
+   int depth = 0;
+   if (n > 0) {
+      /* the sort rounds of formBVH (bvh.cpp:46-72).  A range is (first, second);
+       * the left half is queued as (start, pow2) -- NOT (start, start + pow2) --
+       * exactly as bvh.cpp:65 does, so it is empty (and skipped, bvh.cpp:126)
+       * whenever start > 0: only prefix ranges and right-hand remainders are ever
+       * re-sorted.  Replicated on purpose; the tree shape and leaf order, and with
+       * them every near-tie outcome, depend on it. */
+      typedef std::pair<int, int> Range;
+      std::vector<Range> cur, nxt;
+      int axis = 0;
+      cur.push_back(Range(0, n));
+      while (!cur.empty()) {
+         for (size_t k = 0; k < cur.size(); k++) {
+            int len = cur[k].second - cur[k].first;
+            if (len > 1) merge_sort_range(&order[(size_t)cur[k].first], &tmp[0], len, b.centers, axis);
+         }
+         while (!cur.empty()) {
+            int start = cur.back().first, end = cur.back().second;
+            cur.pop_back();
+            if (end - start > 2) {
+               int p2 = 2;
+               while (p2 * 2 < end - start) p2 *= 2;
+               nxt.push_back(Range(start, p2));
+               nxt.push_back(Range(start + p2, end));
+            }
+         }
+         cur.swap(nxt);
+         axis = (axis + 1) % 3;
+      }
+
+      /* bottom-up pairing: setupBVHNodes (bvh.cpp:179-192), then one
+       * convergeBVHNodes per level (bvh.cpp:88-94, 194-214) */
+      std::vector<TreeNode> pool;
+      pool.reserve((size_t)(2 * n));
+      auto leaf = [&](int prim) { pool.push_back(TreeNode{-1, -1, prim, b.boxes[(size_t)prim]}); return (int)pool.size() - 1; };
+      auto join = [&](int l, int r) { pool.push_back(TreeNode{l, r, -1, merged(pool[(size_t)l].bb, pool[(size_t)r].bb)}); return (int)pool.size() - 1; };
+      int width = (n - 1) / 2 + 1;
+      std::vector<int> level((size_t)width), up((size_t)width);
+      for (int i = 0; i < width; i++) {
+         if (2 * i + 1 < n) { int l = leaf(order[(size_t)(2 * i)]); int r = leaf(order[(size_t)(2 * i + 1)]); level[(size_t)i] = join(l, r); }
+         else level[(size_t)i] = leaf(order[(size_t)(2 * i)]);
+      }
+      for (int left_n = width; left_n > 1; left_n = (left_n - 1) / 2 + 1) {
+         int m = (left_n - 1) / 2 + 1;
+         for (int i = 0; i < m; i++) {
+            if (2 * i + 1 < left_n) up[(size_t)i] = join(level[(size_t)(2 * i)], level[(size_t)(2 * i + 1)]);
+            else up[(size_t)i] = level[(size_t)(2 * i)];
+         }
+         level.swap(up);
+      }
+      int root_node = level[0];
+      if (pool[(size_t)root_node].prim >= 0) {
+         root = ~pool[(size_t)root_node].prim;    /* a one-primitive scene: the root is a leaf */
+      } else {
+         flatten_tree(pool, root_node, flat, &depth);
+         root = 0;
+      }
+   }
+
+   std::vector<rt_dev_light> lights((size_t)d->n_lights);
+   for (int i = 0; i < d->n_lights; i++) {
+      memset(&lights[(size_t)i], 0, sizeof(rt_dev_light));
+      memcpy(lights[(size_t)i].pos, d->lights[i].pos, 12);
+      memcpy(lights[(size_t)i].clr, d->lights[i].clr, 12);
+   }
+
+   out->n_prims = n; out->n_planes = d->n_planes; out->n_lights = d->n_lights;
+   out->n_nodes = (int32_t)flat.size(); out->n_materials = (int32_t)b.materials.size();
+   out->root = root; out->tree_depth = depth; out->any_xform = b.any_xform;
+   out->nodes = copy_out(flat);
+   out->prims = copy_out(b.prims);
+   out->xforms = copy_out(b.xforms);
+   out->shades = copy_out(b.shades);
+   out->planes = copy_out(planes);
+   out->materials = copy_out(b.materials);
+   out->lights = copy_out(lights);
+   order.resize((size_t)n);
+   out->leaf_order = copy_out(order);
+   return RT_OK;
+}
+
+extern "C" void rt_flat_scene_free(rt_flat_scene *fs)
+{
+   if (!fs) return;
+   free(fs->nodes); free(fs->prims); free(fs->xforms); free(fs->shades); free(fs->planes);
+   free(fs->materials); free(fs->lights); free(fs->leaf_order);
+   memset(fs, 0, sizeof *fs);
+}

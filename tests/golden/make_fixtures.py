@@ -1,0 +1,128 @@
+"""Regenerates the committed fixtures under tests/golden/ (run in the build container only).
+
+Inputs come from the reference checkout at /root/reference and from the reference's own parser /
+classes compiled into oracle/_ref/libref.so (recipe: oracle/Makefile); nothing here reads or copies
+reference source text.
+
+  scenes/<name>.npz   the scene description the REFERENCE'S parser produces for <name>.pov
+                      (flat arrays, see raytracer_amd/scene.py) -- input fixtures for parity tests
+  tga/<name>.npz      pixels of the reference's own <name>.tga render (loose goldens: made by the
+                      CUDA build with fast-math and cuRAND jitter)
+  bvh_trace_2852.txt  the sort-range trace the reference keeps in its `output` file
+  pov/*.expected.npz  what the reference's parser makes of the hand-written tests/golden/pov/*.pov
+  classes.npz         known answers of the reference's primitive / shader classes on seeded inputs
+"""
+import ctypes as C
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import orclib  # noqa: E402
+from raytracer_amd import abi  # noqa: E402
+
+REF = orclib.REFERENCE_DIR
+SCENES = ["simple", "simple_reflect", "simple_reflect2", "simple_refract", "simple_spec", "simple_tri", "simple_cam",
+          "recurse_simp", "recurse_simp2", "transforms", "box", "final1", "final2", "cornell", "valentine",
+          "ugly_part", "evil", "bunny_small_tris", "bunny", "dragon_large_tris", "balls2", "iceBot"]
+TGAS = ["recurse_simp2", "valentine", "final1", "simple_refract", "bunny", "dragon_large_tris", "balls2"]
+fp = orclib.fp
+
+
+def read_tga(path):
+    b = open(path, "rb").read()
+    w, h = b[12] | b[13] << 8, b[14] | b[15] << 8
+    bgr = np.frombuffer(b, np.uint8, w * h * 3, 18).reshape(h, w, 3)
+    return np.ascontiguousarray(bgr[:, :, ::-1])      # rows bottom->top as stored, RGB
+
+
+def main():
+    manifest = {"scenes": {}, "tga": {}, "pov": {}}
+    for name in SCENES:
+        sd = orclib.ref_parse(os.path.join(REF, name + ".pov"))
+        sd.save(os.path.join(HERE, "scenes", name + ".npz"))
+        manifest["scenes"][name] = sd.counts()
+    for name in TGAS:
+        img = read_tga(os.path.join(REF, name + ".tga"))
+        np.savez_compressed(os.path.join(HERE, "tga", name + ".npz"), rgb=img)
+        manifest["tga"][name] = list(img.shape)
+    with open(os.path.join(REF, "output")) as f:
+        open(os.path.join(HERE, "bvh_trace_2852.txt"), "w").write(f.read())
+    for pov in sorted(glob.glob(os.path.join(HERE, "pov", "*.pov"))):
+        base = os.path.splitext(os.path.basename(pov))[0]
+        try:
+            sd = orclib.ref_parse(pov)
+            sd.save(os.path.join(HERE, "pov", base + ".expected.npz"))
+            manifest["pov"][base] = sd.counts()
+        except RuntimeError as e:
+            manifest["pov"][base] = {"error": str(e)}
+
+    # known answers of the reference's classes on seeded inputs
+    rng = np.random.default_rng(20261111)
+    out = {}
+    for name in ["transforms", "box", "cornell", "bunny_small_tris", "iceBot", "balls2"]:
+        sd = orclib.ref_parse(os.path.join(REF, name + ".pov"))
+        desc, keep = sd.to_desc()
+        rs = orclib.ref().ref_scene_create(C.byref(desc))
+        nprim = sd.n_bvh_prims + len(sd.planes)
+        prims = rng.choice(nprim, min(nprim, 48), replace=False).astype(np.int32)
+        c3 = np.zeros(3, np.float32)
+        rays = np.zeros((len(prims), 8, 6), np.float32)
+        ts = np.zeros((len(prims), 8), np.float32)
+        nrm = np.zeros((len(prims), 8, 3), np.float32)
+        bbox = np.zeros((len(prims), 6), np.float32)
+        cen = np.zeros((len(prims), 3), np.float32)
+        for i, p in enumerate(prims):
+            p = int(p)
+            orclib.ref().ref_prim_center(rs, p, c3.ctypes.data_as(fp))
+            cen[i] = c3
+            a, b = np.zeros(3, np.float32), np.zeros(3, np.float32)
+            orclib.ref().ref_prim_bbox(rs, p, a.ctypes.data_as(fp), b.ctypes.data_as(fp))
+            bbox[i, :3], bbox[i, 3:] = a, b
+            for k in range(8):
+                o = rng.normal(0, 5, 3).astype(np.float32)
+                target = c3 if p < sd.n_bvh_prims else rng.normal(0, 3, 3).astype(np.float32)
+                d = (target + rng.normal(0, 0.02, 3).astype(np.float32) - o).astype(np.float32)
+                rays[i, k, :3], rays[i, k, 3:] = o, d
+                t = orclib.ref().ref_prim_intersect(rs, p, o.ctypes.data_as(fp), d.ctypes.data_as(fp))
+                ts[i, k] = t
+                n = np.zeros(3, np.float32)
+                if t > 0:
+                    orclib.ref().ref_prim_normal(rs, p, o.ctypes.data_as(fp), d.ctypes.data_as(fp), C.c_float(t), n.ctypes.data_as(fp))
+                nrm[i, k] = n
+        orclib.ref().ref_scene_destroy(rs)
+        out.update({f"{name}_prims": prims, f"{name}_rays": rays, f"{name}_t": ts, f"{name}_normal": nrm,
+                    f"{name}_bbox": bbox, f"{name}_center": cen})
+    # shaders
+    n = 512
+    sh_in = np.zeros((n, 20), np.float32)
+    sh_out = np.zeros((2, n, 3), np.float32)
+    for i in range(n):
+        clr, lc = rng.random(3), rng.random(3) * 1.5
+        amb, dif, spec = rng.random(3)
+        rough = rng.choice([0.05, 0.01, 0.1, 0.3, 1.0, 10.0])
+        v = rng.normal(size=(3, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+        row = np.concatenate([clr, [amb, dif, spec, rough], v[0], v[1], lc, v[2], [i % 3 == 0]]).astype(np.float32)
+        sh_in[i] = row
+        for st in (0, 1):
+            o3 = np.zeros(3, np.float32)
+            r = row
+            orclib.ref().ref_shade(st, r[0:3].copy().ctypes.data_as(fp), C.c_float(r[3]), C.c_float(r[4]), C.c_float(r[5]), C.c_float(r[6]),
+                                   r[7:10].copy().ctypes.data_as(fp), r[10:13].copy().ctypes.data_as(fp), r[13:16].copy().ctypes.data_as(fp),
+                                   r[16:19].copy().ctypes.data_as(fp), int(r[19]), o3.ctypes.data_as(fp))
+            sh_out[st, i] = o3
+    out["shade_in"], out["shade_out"] = sh_in, sh_out
+    np.savez_compressed(os.path.join(HERE, "classes.npz"), **out)
+    json.dump(manifest, open(os.path.join(HERE, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(manifest, indent=1)[:600])
+
+
+if __name__ == "__main__":
+    main()
