@@ -133,8 +133,14 @@ typedef struct rt_stats {
    float ms_total;              /* first extend launch -> resolve completion */
    float ms_extend, ms_shadow, ms_shade, ms_combine, ms_resolve;
    int32_t launches_extend, launches_shadow;
-   /* traversal work counters (only filled when the scene was created with RT_SCENE_COUNTERS) */
+   /* traversal work counters (only filled when the scene was created with RT_SCENE_COUNTERS):
+    * 64-byte node records fetched, primitive records tested, near-tie events -- for the
+    * extend launches and for the shadow launches */
    uint64_t node_visits, prim_tests, tie_events;
+   uint64_t node_visits_shadow, prim_tests_shadow, tie_events_shadow;
+   /* wave-level step counts (one per wave per executed node step / leaf step): lane utilisation of
+    * the traversal loop = node_visits / (64 * wave_node_steps) */
+   uint64_t wave_node_steps, wave_leaf_steps, wave_node_steps_shadow, wave_leaf_steps_shadow;
 } rt_stats;
 
 typedef struct rt_scene_info {

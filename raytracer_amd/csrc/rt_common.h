@@ -72,6 +72,7 @@ typedef struct rt_flat_scene {
    rt_dev_light *lights;       /* n_lights */
    int32_t *leaf_order;        /* n_prims: geomList after formBVH's sort rounds */
    int32_t any_xform;
+   int32_t bounds_in_range;    /* every node bound is finite with magnitude <= 2^40 (or zero) */
 } rt_flat_scene;
 
 #ifdef __cplusplus

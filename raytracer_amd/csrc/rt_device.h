@@ -75,67 +75,61 @@ __device__ __forceinline__ Ray ray_transform(const Ray &r, const rt_dev_xform &m
  * ~10 instructions; with y = RN(1/d) computed once per ray (a true division)
  * two residual corrections give RN(a/d) in 5 (Markstein: q' = q + (a - d*q)*y
  * is correctly rounded once q is within an ulp and y = RN(1/d)).
- * Valid while a, d, the quotient and the residuals stay normal; rays whose
- * origin or direction is outside [2^-60, 2^60] take the plain a/d path. */
-template <bool FAST>
+ * Valid while a, d, the quotient and the residuals stay normal; a wave with a
+ * ray whose origin or direction is outside [2^-40, 2^40] (zero allowed for the
+ * origin) takes the literal path below instead. */
 __device__ __forceinline__ float rt_div(float a, float d, float y)
 {
-   if (FAST) {
-      float q0 = a * y;
-      float r0 = __builtin_fmaf(-d, q0, a);
-      float q1 = __builtin_fmaf(r0, y, q0);
-      float r1 = __builtin_fmaf(-d, q1, a);
-      return __builtin_fmaf(r1, y, q1);
-   } else {
-      return a / d;
-   }
+   float q0 = a * y;
+   float r0 = __builtin_fmaf(-d, q0, a);
+   float q1 = __builtin_fmaf(r0, y, q0);
+   float r1 = __builtin_fmaf(-d, q1, a);
+   return __builtin_fmaf(r1, y, q1);
 }
 
 __device__ __forceinline__ bool in_div_range(float v)
 {
    float a = fabsf(v);
-   return a == 0.0f || (a >= 8.673617379884035e-19f && a <= 1.152921504606847e18f);   /* 2^-60 .. 2^60 */
+   return a >= 9.094947017729282e-13f && a <= 1.099511627776e12f;   /* 2^-40 .. 2^40 */
 }
 
 /* per-ray constants of the slab test */
 struct RayCtx {
    Ray r;
-   float yx, yy, yz;      /* RN(1/d) per axis (unused where the axis is parallel) */
-   bool px, py, pz;       /* isFloatZero(d.axis), GeometryUtil.h:16,23,30 */
-   bool fast;             /* all values inside rt_div's safe range */
+   float yx, yy, yz;      /* RN(1/d) per axis */
+   bool fast;             /* no axis-parallel component and every value inside rt_div's safe range */
 };
 
 __device__ __forceinline__ RayCtx make_ctx(const Ray &r)
 {
    RayCtx c;
    c.r = r;
-   c.px = is_zero(r.d.x); c.py = is_zero(r.d.y); c.pz = is_zero(r.d.z);
    c.yx = 1.0f / r.d.x; c.yy = 1.0f / r.d.y; c.yz = 1.0f / r.d.z;
-   c.fast = in_div_range(r.o.x) && in_div_range(r.o.y) && in_div_range(r.o.z) &&
-            (c.px || in_div_range(r.d.x)) && (c.py || in_div_range(r.d.y)) && (c.pz || in_div_range(r.d.z));
+   /* |d| >= 2^-40 alone would admit the reference's "parallel" axes (|d| < 1e-4, GeometryUtil.h:16,23,30) */
+   bool par = is_zero(r.d.x) || is_zero(r.d.y) || is_zero(r.d.z);
+   c.fast = !par && (r.o.x == 0.0f || in_div_range(r.o.x)) && (r.o.y == 0.0f || in_div_range(r.o.y)) &&
+            (r.o.z == 0.0f || in_div_range(r.o.z)) && in_div_range(r.d.x) && in_div_range(r.d.y) && in_div_range(r.d.z);
    return c;
 }
 
-/* boxIntersect, GeometryUtil.h:9-51 */
-template <bool FAST>
-__device__ __forceinline__ float slab_test(const RayCtx &c, float mnx, float mny, float mnz,
-                                           float mxx, float mxy, float mxz)
+/* boxIntersect, GeometryUtil.h:9-51, literally (any ray, true divisions) */
+__device__ __forceinline__ float slab_literal(const Ray &r, float mnx, float mny, float mnz,
+                                              float mxx, float mxy, float mxz)
 {
-   const Ray &r = c.r;
    bool miss = false;
    float tXmin = -FLT_MAX, tYmin = -FLT_MAX, tZmin = -FLT_MAX;
    float tXmax = FLT_MAX, tYmax = FLT_MAX, tZmax = FLT_MAX;
-   if (!c.px) {
-      tXmin = rt_div<FAST>(mnx - r.o.x, r.d.x, c.yx);
-      tXmax = rt_div<FAST>(mxx - r.o.x, r.d.x, c.yx);
+   if (!is_zero(r.d.x)) {
+      tXmin = (mnx - r.o.x) / r.d.x;
+      tXmax = (mxx - r.o.x) / r.d.x;
    } else if (r.o.x < mnx || r.o.x > mxx) miss = true;
-   if (!c.py) {
-      tYmin = rt_div<FAST>(mny - r.o.y, r.d.y, c.yy);
-      tYmax = rt_div<FAST>(mxy - r.o.y, r.d.y, c.yy);
+   if (!is_zero(r.d.y)) {
+      tYmin = (mny - r.o.y) / r.d.y;
+      tYmax = (mxy - r.o.y) / r.d.y;
    } else if (r.o.y < mny || r.o.y > mxy) miss = true;
-   if (!c.pz) {
-      tZmin = rt_div<FAST>(mnz - r.o.z, r.d.z, c.yz);
-      tZmax = rt_div<FAST>(mxz - r.o.z, r.d.z, c.yz);
+   if (!is_zero(r.d.z)) {
+      tZmin = (mnz - r.o.z) / r.d.z;
+      tZmax = (mxz - r.o.z) / r.d.z;
    } else if (r.o.z < mnz || r.o.z > mxz) miss = true;
 
    float xl = tXmin > tXmax ? tXmax : tXmin, xh = tXmin > tXmax ? tXmin : tXmax;
@@ -146,6 +140,31 @@ __device__ __forceinline__ float slab_test(const RayCtx &c, float mnx, float mny
    bool inside = r.o.x > mnx && r.o.x < mxx && r.o.y > mny && r.o.y < mxy && r.o.z > mnz && r.o.z < mxz;
    float res = inside ? tSmallestMax : (tBiggestMin < tSmallestMax ? tBiggestMin : -1.0f);
    return miss ? -1.0f : res;
+}
+
+/* boxIntersect for a ray with no parallel axis and in-range values: same bits, fewer instructions.
+ *  - the three quotient pairs are never NaN, so min/max order them exactly as the reference's swaps do
+ *    and max3/min3 equal its mymax/mymin chains;
+ *  - the origin is strictly inside the box exactly when every axis has lo < 0 < hi, i.e. when
+ *    tBiggestMin < 0 < tSmallestMax (a difference of two floats keeps its sign, and the quotient of an
+ *    in-range pair cannot underflow), which replaces the six coordinate comparisons. */
+__device__ __forceinline__ float slab_fast(const RayCtx &c, float mnx, float mny, float mnz,
+                                           float mxx, float mxy, float mxz)
+{
+   const Ray &r = c.r;
+   float x1 = rt_div(mnx - r.o.x, r.d.x, c.yx), x2 = rt_div(mxx - r.o.x, r.d.x, c.yx);
+   float y1 = rt_div(mny - r.o.y, r.d.y, c.yy), y2 = rt_div(mxy - r.o.y, r.d.y, c.yy);
+   float z1 = rt_div(mnz - r.o.z, r.d.z, c.yz), z2 = rt_div(mxz - r.o.z, r.d.z, c.yz);
+   float A = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+   float B = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+   return (A < 0.0f && B > 0.0f) ? B : (A < B ? A : -1.0f);
+}
+
+template <bool FAST>
+__device__ __forceinline__ float slab_test(const RayCtx &c, float mnx, float mny, float mnz,
+                                           float mxx, float mxy, float mxz)
+{
+   return FAST ? slab_fast(c, mnx, mny, mnz, mxx, mxy, mxz) : slab_literal(c.r, mnx, mny, mnz, mxx, mxy, mxz);
 }
 
 /* Sphere::intersects, Sphere.h:42-66 (ray already in object space) */

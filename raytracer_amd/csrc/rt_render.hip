@@ -51,6 +51,7 @@ struct DScene {
    const rt_material *materials;
    const rt_dev_light *lights;
    int n_prims, n_planes, n_lights, root;
+   int fast_ok;      /* every BVH bound is finite and below 2^40 in magnitude */
 };
 
 struct DCamera {
@@ -83,7 +84,9 @@ struct ShadeNode {
 };
 
 enum { ST_SHADOW_TRACED = 0, ST_SHADOW_SKIPPED, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES, ST_PRIMARY,
-       ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_COUNT };
+       ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
+       ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_WAVE_NODE_STEPS_SHADOW, ST_WAVE_LEAF_STEPS_SHADOW,
+       ST_COUNT };
 
 /* ======================================================================= */
 /* record loads                                                             */
@@ -123,8 +126,7 @@ __device__ __forceinline__ float prim_intersect(const DScene &sc, int prim, cons
    if (p.m.x == RT_PRIM_SPHERE) {
       return sphere_hit(r, mk3(p.a.x, p.a.y, p.a.z), p.a.w);
    } else if (p.m.x == RT_PRIM_BOX) {
-      RayCtx c = make_ctx(r);
-      return slab_test<false>(c, p.a.x, p.a.y, p.a.z, p.a.w, p.b.x, p.b.y);
+      return slab_literal(r, p.a.x, p.a.y, p.a.z, p.a.w, p.b.x, p.b.y);
    } else {
       return triangle_hit(r, mk3(p.a.x, p.a.y, p.a.z), mk3(p.a.w, p.b.x, p.b.y), mk3(p.b.z, p.b.w, p.c.x),
                           mk3(p.c.y, p.c.z, p.c.w));
@@ -212,7 +214,8 @@ template <bool FAST, bool COUNT>
 __device__ __forceinline__ void traverse_bvh(const DScene &sc, const RayCtx &c, float toBeat,
                                              StackEntry *stack, int stride,
                                              int &closest, float &t, bool &early,
-                                             unsigned &n_visits, unsigned &n_prim_tests, unsigned &n_ties)
+                                             unsigned &n_visits, unsigned &n_prim_tests, unsigned &n_ties,
+                                             unsigned &w_node_steps, unsigned &w_leaf_steps)
 {
    int cur = sc.root;
    int sp = 0;
@@ -222,7 +225,11 @@ __device__ __forceinline__ void traverse_bvh(const DScene &sc, const RayCtx &c, 
       while (!done && cur >= 0) {
          float4 a, b, cc, d;
          load_node(sc.nodes, cur, a, b, cc, d);
-         if (COUNT) n_visits++;
+         if (COUNT) {
+            n_visits++;
+            /* one tick per wave per executed step: only the first active lane counts */
+            if (__lane_id() == (unsigned)__ffsll((long long)__ballot(1)) - 1) w_node_steps++;
+         }
          float left = slab_test<FAST>(c, a.x, a.y, a.z, a.w, b.x, b.y);
          float right = slab_test<FAST>(c, b.z, b.w, cc.x, cc.y, cc.z, cc.w);
          int li = __float_as_int(d.x), ri = __float_as_int(d.y);
@@ -248,7 +255,10 @@ __device__ __forceinline__ void traverse_bvh(const DScene &sc, const RayCtx &c, 
       if (!done) {
          /* leaf: cur = ~prim */
          int prim = ~cur;
-         if (COUNT) n_prim_tests++;
+         if (COUNT) {
+            n_prim_tests++;
+            if (__lane_id() == (unsigned)__ffsll((long long)__ballot(1)) - 1) w_leaf_steps++;
+         }
          float dist = prim_intersect(sc, prim, c.r);
          bool take = false;
          if (is_equal(t, dist)) {
@@ -276,19 +286,20 @@ __device__ __forceinline__ void traverse_bvh(const DScene &sc, const RayCtx &c, 
 
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &ray, float toBeat, StackEntry *stack, int stride,
-                                            bool active, int &out_prim, float &out_t, unsigned long long *stats)
+                                            bool active, int &out_prim, float &out_t, unsigned long long *stats,
+                                            int stat_base)
 {
    float t = FLT_MAX;
    int closest = -1;
    bool early = false;
-   unsigned nv = 0, np = 0, nt = 0;
+   unsigned nv = 0, np = 0, nt = 0, wn = 0, wl = 0;
    RayCtx c = make_ctx(ray);
    /* both division paths give the correctly rounded quotient; the plain one is taken by the
     * whole wave when any lane's values are outside the range where the short form is exact */
-   bool wave_fast = __all(c.fast || !active) != 0;
+   bool wave_fast = sc.fast_ok && __all(c.fast || !active) != 0;
    if (active) {
-      if (wave_fast) traverse_bvh<true, COUNT>(sc, c, toBeat, stack, stride, closest, t, early, nv, np, nt);
-      else traverse_bvh<false, COUNT>(sc, c, toBeat, stack, stride, closest, t, early, nv, np, nt);
+      if (wave_fast) traverse_bvh<true, COUNT>(sc, c, toBeat, stack, stride, closest, t, early, nv, np, nt, wn, wl);
+      else traverse_bvh<false, COUNT>(sc, c, toBeat, stack, stride, closest, t, early, nv, np, nt, wn, wl);
       if (!early) {
          /* planes: kernel.cu:189-196 (no tie rule, no toBeat exit) */
          for (int k = 0; k < sc.n_planes; k++) {
@@ -298,9 +309,11 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &ray, fl
       }
    }
    if (COUNT) {
-      atomicAdd(&stats[ST_NODE_VISITS], (unsigned long long)nv);
-      atomicAdd(&stats[ST_PRIM_TESTS], (unsigned long long)np);
-      atomicAdd(&stats[ST_TIES], (unsigned long long)nt);
+      atomicAdd(&stats[stat_base + 0], (unsigned long long)nv);
+      atomicAdd(&stats[stat_base + 1], (unsigned long long)np);
+      atomicAdd(&stats[stat_base + 2], (unsigned long long)nt);
+      atomicAdd(&stats[stat_base + 3], (unsigned long long)wn);
+      atomicAdd(&stats[stat_base + 4], (unsigned long long)wl);
    }
    out_prim = closest;
    out_t = t;
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene sc, DCamera cam, DGr
    bool active = i < n && level_ray(primary != 0, cam, g, queue, i, ray);
    float tb = (active && to_beat) ? to_beat[i] : -FLT_MAX;
    int prim; float t;
-   closest_hit<COUNT>(sc, ray, tb, lds_stack + threadIdx.x, RT_BLOCK, active, prim, t, stats);
+   closest_hit<COUNT>(sc, ray, tb, lds_stack + threadIdx.x, RT_BLOCK, active, prim, t, stats, ST_NODE_VISITS);
    if (i < n) { Hit h; h.prim = active ? prim : -1; h.t = t; hits[i] = h; }
    if (primary && active) atomicAdd(&stats[ST_PRIMARY], 1ULL);
 }
@@ -423,7 +436,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene sc, DCamera cam, DGr
       }
    }
    int prim; float t;
-   closest_hit<COUNT>(sc, feeler, param, lds_stack + threadIdx.x, RT_BLOCK, active, prim, t, stats);
+   closest_hit<COUNT>(sc, feeler, param, lds_stack + threadIdx.x, RT_BLOCK, active, prim, t, stats, ST_NODE_VISITS_SHADOW);
    if (i < n) flags[(long long)light * n + i] = (active && less_than(t, param)) ? 1 : 0;   /* kernel.cu:206 */
    if (active) atomicAdd(&stats[ST_SHADOW_TRACED], 1ULL);
 }
@@ -772,6 +785,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->d.planes = (const rt_dev_plane *)(b + off[4]); s->d.materials = (const rt_material *)(b + off[5]);
    s->d.lights = (const rt_dev_light *)(b + off[6]);
    s->d.n_prims = h.n_prims; s->d.n_planes = h.n_planes; s->d.n_lights = h.n_lights; s->d.root = h.root;
+   s->d.fast_ok = h.bounds_in_range;
 
    if (hipMalloc((void **)&s->d_counts, 64 * sizeof(unsigned)) != hipSuccess ||
        hipMalloc((void **)&s->d_stats, ST_COUNT * sizeof(unsigned long long)) != hipSuccess ||
@@ -1093,6 +1107,10 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    st.rays_total = st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract;
    st.samples = st.rays_primary;
    st.node_visits = s->h_stats[ST_NODE_VISITS]; st.prim_tests = s->h_stats[ST_PRIM_TESTS]; st.tie_events = s->h_stats[ST_TIES];
+   st.node_visits_shadow = s->h_stats[ST_NODE_VISITS_SHADOW]; st.prim_tests_shadow = s->h_stats[ST_PRIM_TESTS_SHADOW];
+   st.tie_events_shadow = s->h_stats[ST_TIES_SHADOW];
+   st.wave_node_steps = s->h_stats[ST_WAVE_NODE_STEPS]; st.wave_leaf_steps = s->h_stats[ST_WAVE_LEAF_STEPS];
+   st.wave_node_steps_shadow = s->h_stats[ST_WAVE_NODE_STEPS_SHADOW]; st.wave_leaf_steps_shadow = s->h_stats[ST_WAVE_LEAF_STEPS_SHADOW];
    if (stats_out) *stats_out = st;
    return RT_OK;
 }

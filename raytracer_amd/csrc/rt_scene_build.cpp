@@ -410,6 +410,12 @@ extern "C" int rt_flatten_scene(const rt_scene_desc *d, rt_flat_scene *out)
    out->n_prims = n; out->n_planes = d->n_planes; out->n_lights = d->n_lights;
    out->n_nodes = (int32_t)flat.size(); out->n_materials = (int32_t)b.materials.size();
    out->root = root; out->tree_depth = depth; out->any_xform = b.any_xform;
+   out->bounds_in_range = 1;
+   for (size_t k = 0; k < flat.size(); k++) {
+      const float *v = flat[k].lmin;   /* lmin, lmax, rmin, rmax are 12 consecutive floats */
+      for (int j = 0; j < 12; j++)
+         if (!(std::fabs(v[j]) <= 1.099511627776e12f)) out->bounds_in_range = 0;
+   }
    out->nodes = copy_out(flat);
    out->prims = copy_out(b.prims);
    out->xforms = copy_out(b.xforms);
