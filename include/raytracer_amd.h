@@ -131,7 +131,8 @@ typedef struct rt_stats {
    uint64_t samples;
    /* device time, ms (HIP events on the render stream) */
    float ms_total;              /* first extend launch -> resolve completion */
-   float ms_extend, ms_shadow, ms_shade, ms_combine, ms_resolve;
+   float ms_extend, ms_shadow, ms_shade, ms_combine, ms_resolve;   /* extend / shadow: the traversal launches alone */
+   float ms_generate, ms_shadow_setup;
    int32_t launches_extend, launches_shadow;
    /* traversal work counters (only filled when the scene was created with RT_SCENE_COUNTERS):
     * 64-byte node records fetched, primitive records tested, near-tie events -- for the

@@ -4,6 +4,7 @@
  * Replaces the reference's rayTrace megakernel and its helpers
  * (kernel.cu:67-382, 466-570) with a wavefront pipeline over ray queues:
  *
+ *   generate primary rays of a batch of tiles into a ray queue    (generateCameraRays, kernel.cu:477-498)
  *   extend   closest hit of every ray of a depth level          (getClosestIntersection, kernel.cu:83-200)
  *   shadow   one any-hit query per (light, shade node)          (isInShadow, kernel.cu:202-207)
  *   shade    material + light sum per node, spawns the          (shadeObject / getReflection / getRefraction,
@@ -17,10 +18,14 @@
  * level, so the final combine evaluates exactly the reference's expression
  * tree (same operands, same order) without recursion or float atomics.
  *
- * Traversal keeps the reference's visiting order (near child first with its
- * `<=` tie rule, deferred sibling re-checked against the current t) because
- * near-ties between primitives are resolved by visiting order.  The per-lane
- * stack of deferred siblings lives in LDS, one column per lane.
+ * extend and shadow are the same persistent-thread traversal kernel (k_trace)
+ * over a ray queue: a wave keeps 64 rays in flight, and as soon as enough of its
+ * lanes have finished it pulls the next rays of the queue into the idle lanes
+ * (one atomic per refill), so long and short rays do not stall each other.
+ * Each ray still walks the tree in the reference's visiting order (near child
+ * first with its `<=` tie rule, deferred sibling re-checked against the current
+ * t) because near-ties between primitives are resolved by visiting order.  The
+ * per-lane stack of deferred siblings lives in LDS, one column per lane.
  */
 #include <hip/hip_runtime.h>
 
@@ -73,7 +78,8 @@ struct DGrid {
 
 struct Hit { int prim; float t; };
 
-struct QRay { float ox, oy, oz, pad0, dx, dy, dz, pad1; };   /* 32 bytes */
+/* queue entry, 32 bytes: origin, early-out threshold (toBeat, kernel.cu:84), direction, valid flag */
+struct QRay { float ox, oy, oz, to_beat, dx, dy, dz; int valid; };
 
 /* result of shading one node: the operands of kernel.cu:375-376 */
 struct ShadeNode {
@@ -87,6 +93,21 @@ enum { ST_SHADOW_TRACED = 0, ST_SHADOW_SKIPPED, ST_REFLECT, ST_REFRACT, ST_SHADE
        ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
        ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_WAVE_NODE_STEPS_SHADOW, ST_WAVE_LEAF_STEPS_SHADOW,
        ST_COUNT };
+
+/* Statistics counters are replicated RT_STAT_REPL times (blocks spread over the replicas, the host
+ * sums them) and bumped once per wave, so that counting does not serialise the kernels on one word. */
+#define RT_STAT_REPL 32
+__device__ __forceinline__ void stat_add(unsigned long long *stats, int which, unsigned long long v)
+{
+   atomicAdd(&stats[which * RT_STAT_REPL + (blockIdx.x & (RT_STAT_REPL - 1))], v);
+}
+/* counts the lanes of the wave for which pred holds; call from converged code */
+__device__ __forceinline__ void stat_count(unsigned long long *stats, int which, bool pred)
+{
+   unsigned long long m = __ballot(pred);
+   unsigned long long all = __ballot(1);
+   if (m && __lane_id() == (unsigned)__ffsll((long long)all) - 1) stat_add(stats, which, (unsigned long long)__popcll(m));
+}
 
 /* ======================================================================= */
 /* record loads                                                             */
@@ -147,15 +168,12 @@ __device__ __forceinline__ float any_intersect(const DScene &sc, int id, const R
    return id < sc.n_prims ? prim_intersect(sc, id, r) : plane_intersect(sc, id - sc.n_prims, r);
 }
 
-/* getNormalAt: Sphere.h:19-24, Triangle.h:24-26, SmoothTriangle.h:31-38, Box.h:42-60, Plane.h:20-22 */
-__device__ F3 normal_at(const DScene &sc, int id, const Ray &ray, float t)
+/* getNormalAt of a BVH primitive: Sphere.h:19-24, Triangle.h:24-26, SmoothTriangle.h:31-38, Box.h:42-60 */
+__device__ __forceinline__ F3 prim_normal_at(const rt_dev_prim *prims, const rt_dev_xform *xforms, const rt_dev_shade *shades,
+                                             int id, const Ray &ray, float t)
 {
-   if (id >= sc.n_prims) {
-      const rt_dev_plane &pl = sc.planes[id - sc.n_prims];
-      return mk3(pl.wsN[0], pl.wsN[1], pl.wsN[2]);
-   }
-   PrimRec p = load_prim(sc.prims, id);
-   const float4 *sp = reinterpret_cast<const float4 *>(sc.shades + id);
+   PrimRec p = load_prim(prims, id);
+   const float4 *sp = reinterpret_cast<const float4 *>(shades + id);
    float4 s0 = sp[0];
    if (p.m.x == RT_PRIM_SPHERE) {
       F3 pos = ray_point(ray, t);
@@ -174,7 +192,7 @@ __device__ F3 normal_at(const DScene &sc, int id, const Ray &ray, float t)
       F3 n1 = mk3(s0.x, s0.y, s0.z), n2 = mk3(s0.w, s1.x, s1.y), n3 = mk3(s1.z, s1.w, s2.x);
       return normalize3(alpha * n1 + beta * n2 + gamma * n3);
    } else {
-      Ray r = ray_transform(ray, load_xform(sc.xforms, id));   /* Box.h:43 transforms unconditionally */
+      Ray r = ray_transform(ray, load_xform(xforms, id));   /* Box.h:43 transforms unconditionally */
       F3 ip = ray_point(r, t);
       F3 mn = mk3(p.a.x, p.a.y, p.a.z), mx = mk3(p.a.w, p.b.x, p.b.y);
       F3 nm;
@@ -193,12 +211,26 @@ __device__ F3 normal_at(const DScene &sc, int id, const Ray &ray, float t)
    }
 }
 
-/* The overlap rule of kernel.cu:108-122: of two hits closer than EQUAL_EPSILON the one
- * whose normal faces the eye more wins.  Rare (a few percent of rays), so kept out of line. */
-__device__ __noinline__ bool tie_prefers_new(const DScene &sc, Ray ray, int old_prim, float old_t, int new_prim, float new_t)
+/* getNormalAt of any primitive id (planes follow the BVH primitives): Plane.h:20-22 */
+__device__ __forceinline__ F3 normal_at(const DScene &sc, int id, const Ray &ray, float t)
 {
-   F3 oldNorm = normal_at(sc, old_prim, ray, old_t);
-   F3 newNorm = normal_at(sc, new_prim, ray, new_t);
+   if (id >= sc.n_prims) {
+      const rt_dev_plane &pl = sc.planes[id - sc.n_prims];
+      return mk3(pl.wsN[0], pl.wsN[1], pl.wsN[2]);
+   }
+   return prim_normal_at(sc.prims, sc.xforms, sc.shades, id, ray, t);
+}
+
+/* The overlap rule of kernel.cu:108-122: of two hits closer than EQUAL_EPSILON the one whose normal
+ * faces the eye more wins.  Rare (a few percent of rays), so kept out of line; it takes the arrays by
+ * value so that the caller's scene view stays in registers. */
+__device__ __noinline__ bool tie_prefers_new(const rt_dev_prim *prims, const rt_dev_xform *xforms, const rt_dev_shade *shades,
+                                             float ox, float oy, float oz, float dx, float dy, float dz,
+                                             int old_prim, float old_t, int new_prim, float new_t)
+{
+   Ray ray; ray.o = mk3(ox, oy, oz); ray.d = mk3(dx, dy, dz);
+   F3 oldNorm = prim_normal_at(prims, xforms, shades, old_prim, ray, old_t);
+   F3 newNorm = prim_normal_at(prims, xforms, shades, new_prim, ray, new_t);
    F3 eye = normalize3(-ray.d);
    float newDot = dot3(eye, newNorm);
    float oldDot = dot3(eye, oldNorm);
@@ -209,114 +241,185 @@ __device__ __noinline__ bool tie_prefers_new(const DScene &sc, Ray ray, int old_
 /* traversal: getClosestIntersection, kernel.cu:83-200                      */
 /* ======================================================================= */
 struct StackEntry { int child; float dist; };
+extern __shared__ StackEntry lds_stack[];
 
-template <bool FAST, bool COUNT>
-__device__ __forceinline__ void traverse_bvh(const DScene &sc, const RayCtx &c, float toBeat,
-                                             StackEntry *stack, int stride,
-                                             int &closest, float &t, bool &early,
-                                             unsigned &n_visits, unsigned &n_prim_tests, unsigned &n_ties,
-                                             unsigned &w_node_steps, unsigned &w_leaf_steps)
+enum { OUT_HIT = 0, OUT_FLAG = 1 };
+
+#define RT_REFILL_IDLE 20   /* pull new rays once this many lanes of the wave are idle */
+#define RT_LEAF_WAIT 12     /* run a primitive step once this many lanes wait at a leaf */
+
+__device__ __forceinline__ QRay load_qray_rec(const QRay *q, unsigned long long i)
 {
-   int cur = sc.root;
-   int sp = 0;
-   bool done = (cur == RT_ROOT_EMPTY);
-   while (!done) {
-      /* descend through internal nodes */
-      while (!done && cur >= 0) {
-         float4 a, b, cc, d;
-         load_node(sc.nodes, cur, a, b, cc, d);
-         if (COUNT) {
-            n_visits++;
-            /* one tick per wave per executed step: only the first active lane counts */
-            if (__lane_id() == (unsigned)__ffsll((long long)__ballot(1)) - 1) w_node_steps++;
-         }
-         float left = slab_test<FAST>(c, a.x, a.y, a.z, a.w, b.x, b.y);
-         float right = slab_test<FAST>(c, b.z, b.w, cc.x, cc.y, cc.z, cc.w);
-         int li = __float_as_int(d.x), ri = __float_as_int(d.y);
-         bool aL = above_zero(left), aR = above_zero(right);
-         if (aR && (right <= left || !aL) && right < t) {
-            if (aL) { stack[sp * stride].child = li; stack[sp * stride].dist = left; sp++; }
-            cur = ri;
-         } else if (aL && (left <= right || !aR) && left < t) {
-            if (aR) { stack[sp * stride].child = ri; stack[sp * stride].dist = right; sp++; }
-            cur = li;
-         } else {
-            /* pop: the reference re-tests the deferred child's box against the current t (kernel.cu:160-176);
-             * the box distance cannot have changed, so it is kept beside the child instead of recomputed */
-            bool found = false;
-            while (sp > 0) {
-               sp--;
-               StackEntry e = stack[sp * stride];
-               if (e.dist < t) { cur = e.child; found = true; break; }
-            }
-            if (!found) done = true;
-         }
-      }
-      if (!done) {
-         /* leaf: cur = ~prim */
-         int prim = ~cur;
-         if (COUNT) {
-            n_prim_tests++;
-            if (__lane_id() == (unsigned)__ffsll((long long)__ballot(1)) - 1) w_leaf_steps++;
-         }
-         float dist = prim_intersect(sc, prim, c.r);
-         bool take = false;
-         if (is_equal(t, dist)) {
-            if (COUNT) n_ties++;
-            if (closest >= 0) take = tie_prefers_new(sc, c.r, closest, t, prim, dist);
-         } else {
-            take = dist < t && above_zero(dist);
-         }
-         if (take) {
-            t = dist; closest = prim;
-            if (t < toBeat) { early = true; done = true; }
-         }
-         if (!done) {
-            bool found = false;
-            while (sp > 0) {
-               sp--;
-               StackEntry e = stack[sp * stride];
-               if (e.dist < t) { cur = e.child; found = true; break; }
-            }
-            if (!found) done = true;
-         }
-      }
-   }
+   const float4 *p = reinterpret_cast<const float4 *>(q + i);
+   float4 a = p[0], b = p[1];
+   QRay r;
+   r.ox = a.x; r.oy = a.y; r.oz = a.z; r.to_beat = a.w; r.dx = b.x; r.dy = b.y; r.dz = b.z; r.valid = __float_as_int(b.w);
+   return r;
+}
+__device__ __forceinline__ void store_qray(QRay *q, unsigned long long i, F3 o, F3 d, float to_beat, int valid)
+{
+   float4 *p = reinterpret_cast<float4 *>(q + i);
+   p[0] = make_float4(o.x, o.y, o.z, to_beat);
+   p[1] = make_float4(d.x, d.y, d.z, __int_as_float(valid));
+}
+__device__ __forceinline__ Ray load_qray(const QRay *q, long long i)
+{
+   QRay e = load_qray_rec(q, (unsigned long long)i);
+   Ray r; r.o = mk3(e.ox, e.oy, e.oz); r.d = mk3(e.dx, e.dy, e.dz);
+   return r;
 }
 
-template <bool COUNT>
-__device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &ray, float toBeat, StackEntry *stack, int stride,
-                                            bool active, int &out_prim, float &out_t, unsigned long long *stats,
-                                            int stat_base)
+/* k_trace: persistent-thread closest-hit / any-hit over a ray queue.
+ *
+ * Lane state is one ray: (ctx, t, closest, cur, sp).  cur >= 0 is an internal node, cur < 0 a leaf
+ * (~cur = primitive).  The wave alternates between
+ *   node steps  -- every lane at an internal node tests the two child boxes of its node
+ *                  (kernel.cu:136-158) and descends / defers / pops,
+ *   leaf steps  -- every lane at a leaf intersects its primitive (kernel.cu:104-134) and pops,
+ * running a leaf step only when RT_LEAF_WAIT lanes are waiting for one (or nothing else can run), and
+ * refills idle lanes from the queue when RT_REFILL_IDLE of them are free.  A ray's own sequence of
+ * operations is exactly that of the reference loop; only the interleaving between rays differs. */
+template <int OUT, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays, unsigned long long n, Hit *hits,
+                                                    unsigned char *flags, unsigned long long *next,
+                                                    unsigned long long *stats, int stat_base)
 {
-   float t = FLT_MAX;
-   int closest = -1;
-   bool early = false;
+   StackEntry *stack = lds_stack + threadIdx.x;
+   const int stride = RT_BLOCK;
+   const unsigned lane = __lane_id();
+   const unsigned long long below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+
+   bool active = false;
+   bool exhausted = false;             /* wave-uniform: the queue has no more rays */
+   RayCtx c;
+   c.r.o = mk3(0, 0, 0); c.r.d = mk3(1, 1, 1); c.yx = c.yy = c.yz = 1.0f; c.fast = true;
+   float t = FLT_MAX, toBeat = -FLT_MAX;
+   int closest = -1, cur = 0, sp = 0;
+   unsigned long long idx = 0;
    unsigned nv = 0, np = 0, nt = 0, wn = 0, wl = 0;
-   RayCtx c = make_ctx(ray);
-   /* both division paths give the correctly rounded quotient; the plain one is taken by the
-    * whole wave when any lane's values are outside the range where the short form is exact */
-   bool wave_fast = sc.fast_ok && __all(c.fast || !active) != 0;
-   if (active) {
-      if (wave_fast) traverse_bvh<true, COUNT>(sc, c, toBeat, stack, stride, closest, t, early, nv, np, nt, wn, wl);
-      else traverse_bvh<false, COUNT>(sc, c, toBeat, stack, stride, closest, t, early, nv, np, nt, wn, wl);
+
+   /* a ray is finished: scan the planes unless it left early (kernel.cu:189-196), write its result */
+   auto finish = [&](bool early) {
       if (!early) {
-         /* planes: kernel.cu:189-196 (no tie rule, no toBeat exit) */
          for (int k = 0; k < sc.n_planes; k++) {
-            float dist = plane_intersect(sc, k, ray);
+            float dist = plane_intersect(sc, k, c.r);
             if (less_than(dist, t) && above_zero(dist)) { closest = sc.n_prims + k; t = dist; }
+         }
+      }
+      if (OUT == OUT_HIT) { Hit h; h.prim = closest; h.t = t; hits[idx] = h; }
+      else flags[idx] = less_than(t, toBeat) ? 1 : 0;            /* kernel.cu:206 */
+      active = false;
+   };
+   /* pop deferred siblings until one is still closer than t (kernel.cu:160-186); none left = done */
+   auto pop = [&]() {
+      bool found = false;
+      while (sp > 0) {
+         sp--;
+         StackEntry e = stack[sp * stride];
+         if (e.dist < t) { cur = e.child; found = true; break; }
+      }
+      if (!found) finish(false);
+   };
+
+   for (;;) {
+      unsigned long long m_active = __ballot(active);
+      int n_idle = 64 - __popcll(m_active);
+      if (!exhausted && n_idle >= RT_REFILL_IDLE) {
+         unsigned long long m_idle = ~m_active;
+         int leader = __ffsll((long long)m_idle) - 1;
+         unsigned long long base = 0;
+         if ((int)lane == leader) base = atomicAdd(next, (unsigned long long)n_idle);
+         base = __shfl(base, leader);
+         if (base + (unsigned long long)n_idle >= n) exhausted = true;
+         if (!active) {
+            unsigned long long my = base + (unsigned long long)__popcll(m_idle & below);
+            if (my < n) {
+               QRay q = load_qray_rec(rays, my);
+               if (q.valid) {
+                  Ray r; r.o = mk3(q.ox, q.oy, q.oz); r.d = mk3(q.dx, q.dy, q.dz);
+                  c = make_ctx(r);
+                  toBeat = q.to_beat; idx = my;
+                  t = FLT_MAX; closest = -1; sp = 0; cur = sc.root;
+                  active = true;
+                  if (cur == RT_ROOT_EMPTY) finish(false);
+               }
+            }
+         }
+         m_active = __ballot(active);
+      }
+      if (m_active == 0) {
+         if (exhausted) break;
+         continue;
+      }
+      bool at_leaf = active && cur < 0;
+      unsigned long long mL = __ballot(at_leaf);
+      unsigned long long mI = m_active & ~mL;
+      if (mI != 0 && __popcll(mL) < RT_LEAF_WAIT) {
+         /* ---- node step ---- */
+         bool in_node = active && cur >= 0;
+         /* both box-test forms give the same bits; the literal one also covers parallel axes and
+          * out-of-range values, so the wave takes it whenever one of its lanes needs it */
+         bool wave_fast = sc.fast_ok && __ballot(in_node && !c.fast) == 0;
+         if (COUNT) wn++;
+         if (in_node) {
+            float4 a, b, cc, d;
+            load_node(sc.nodes, cur, a, b, cc, d);
+            if (COUNT) nv++;
+            float left, right;
+            if (wave_fast) {
+               left = slab_fast(c, a.x, a.y, a.z, a.w, b.x, b.y);
+               right = slab_fast(c, b.z, b.w, cc.x, cc.y, cc.z, cc.w);
+            } else {
+               left = slab_literal(c.r, a.x, a.y, a.z, a.w, b.x, b.y);
+               right = slab_literal(c.r, b.z, b.w, cc.x, cc.y, cc.z, cc.w);
+            }
+            int li = __float_as_int(d.x), ri = __float_as_int(d.y);
+            bool aL = above_zero(left), aR = above_zero(right);
+            if (aR && (right <= left || !aL) && right < t) {
+               if (aL) { StackEntry e; e.child = li; e.dist = left; stack[sp * stride] = e; sp++; }
+               cur = ri;
+            } else if (aL && (left <= right || !aR) && left < t) {
+               if (aR) { StackEntry e; e.child = ri; e.dist = right; stack[sp * stride] = e; sp++; }
+               cur = li;
+            } else {
+               pop();
+            }
+         }
+      } else {
+         /* ---- leaf step ---- */
+         if (COUNT) wl++;
+         if (at_leaf) {
+            int prim = ~cur;
+            if (COUNT) np++;
+            float dist = prim_intersect(sc, prim, c.r);
+            bool take = false;
+            if (is_equal(t, dist)) {
+               if (COUNT) nt++;
+               if (closest >= 0)
+                  take = tie_prefers_new(sc.prims, sc.xforms, sc.shades, c.r.o.x, c.r.o.y, c.r.o.z, c.r.d.x, c.r.d.y, c.r.d.z,
+                                         closest, t, prim, dist);
+            } else {
+               take = dist < t && above_zero(dist);
+            }
+            bool early = false;
+            if (take) {
+               t = dist; closest = prim;
+               early = t < toBeat;                       /* kernel.cu:117-121, 128-132 */
+            }
+            if (early) finish(true);
+            else pop();
          }
       }
    }
    if (COUNT) {
-      atomicAdd(&stats[stat_base + 0], (unsigned long long)nv);
-      atomicAdd(&stats[stat_base + 1], (unsigned long long)np);
-      atomicAdd(&stats[stat_base + 2], (unsigned long long)nt);
-      atomicAdd(&stats[stat_base + 3], (unsigned long long)wn);
-      atomicAdd(&stats[stat_base + 4], (unsigned long long)wl);
+      stat_add(stats, stat_base + 0, (unsigned long long)nv);
+      stat_add(stats, stat_base + 1, (unsigned long long)np);
+      stat_add(stats, stat_base + 2, (unsigned long long)nt);
+      if (lane == 0) {
+         stat_add(stats, stat_base + 3, (unsigned long long)wn);
+         stat_add(stats, stat_base + 4, (unsigned long long)wl);
+      }
    }
-   out_prim = closest;
-   out_t = t;
 }
 
 /* ======================================================================= */
@@ -329,7 +432,7 @@ __device__ __forceinline__ unsigned hash32(unsigned x)
 }
 
 /* sample slot -> sample coordinates on the (W*s) x (H*s) grid.  A tile's samples are
- * numbered in 8x8 patches so that one wave covers a compact square of the image. */
+ * numbered in 8x8 patches so that 64 consecutive slots cover a compact square of the image. */
 __device__ __forceinline__ bool slot_to_sample(const DGrid &g, long long slot, int &X, int &Y)
 {
    int per_tile = g.ts * g.ts;
@@ -365,80 +468,58 @@ __device__ __forceinline__ Ray camera_ray(const DCamera &cam, const DGrid &g, in
    return r;
 }
 
-__device__ __forceinline__ Ray load_qray(const QRay *q, long long i)
-{
-   const float4 *p = reinterpret_cast<const float4 *>(q + i);
-   float4 a = p[0], b = p[1];
-   Ray r; r.o = mk3(a.x, a.y, a.z); r.d = mk3(b.x, b.y, b.z);
-   return r;
-}
-
-/* the ray of node i of a level: regenerated for level 0, read from the queue otherwise */
-__device__ __forceinline__ bool level_ray(bool primary, const DCamera &cam, const DGrid &g, const QRay *queue,
-                                          long long i, Ray &r)
-{
-   if (primary) {
-      int X, Y;
-      if (!slot_to_sample(g, i, X, Y)) return false;
-      r = camera_ray(cam, g, X, Y);
-      return true;
-   }
-   r = load_qray(queue, i);
-   return true;
-}
-
 /* ======================================================================= */
 /* kernels                                                                  */
 /* ======================================================================= */
-extern __shared__ StackEntry lds_stack[];
 
-/* extend: one closest-hit query per ray of the level */
-template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene sc, DCamera cam, DGrid g, int primary, const QRay *queue,
-                                                     const float *to_beat, long long n, Hit *hits,
-                                                     unsigned long long *stats)
+/* generate: the primary ray of every sample slot of the batch (slots outside the frame are invalid) */
+__global__ __launch_bounds__(RT_BLOCK) void k_generate(DCamera cam, DGrid g, long long n, QRay *queue, Hit *hits,
+                                                       unsigned long long *stats)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-   Ray ray; ray.o = mk3(0, 0, 0); ray.d = mk3(0, 0, 1);
-   bool active = i < n && level_ray(primary != 0, cam, g, queue, i, ray);
-   float tb = (active && to_beat) ? to_beat[i] : -FLT_MAX;
-   int prim; float t;
-   closest_hit<COUNT>(sc, ray, tb, lds_stack + threadIdx.x, RT_BLOCK, active, prim, t, stats, ST_NODE_VISITS);
-   if (i < n) { Hit h; h.prim = active ? prim : -1; h.t = t; hits[i] = h; }
-   if (primary && active) atomicAdd(&stats[ST_PRIMARY], 1ULL);
+   int X = 0, Y = 0;
+   bool valid = i < n && slot_to_sample(g, i, X, Y);
+   if (i < n) {
+      Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
+      if (valid) r = camera_ray(cam, g, X, Y);
+      store_qray(queue, (unsigned long long)i, r.o, r.d, -FLT_MAX, valid ? 1 : 0);
+      if (!valid) { Hit h; h.prim = -1; h.t = FLT_MAX; hits[i] = h; }
+   }
+   stat_count(stats, ST_PRIMARY, valid);
 }
 
-/* shadow: thread (light = blockIdx.y, node = x).  flags[light*n + node] = inShadow */
-template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DScene sc, DCamera cam, DGrid g, int primary, const QRay *queue,
-                                                     const Hit *hits, long long n, unsigned char *flags,
-                                                     unsigned long long *stats)
+/* shadow set-up: the feeler of (light = blockIdx.y, node = x) into the shadow queue at light*n + node */
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow_setup(DScene sc, const QRay *queue, const Hit *hits, long long n,
+                                                           QRay *shadow_queue, unsigned char *flags,
+                                                           unsigned long long *stats)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
    int light = blockIdx.y;
-   Ray ray; ray.o = mk3(0, 0, 0); ray.d = mk3(0, 0, 1);
-   bool active = false;
-   float param = -1.0f;
-   Ray feeler = ray;
+   bool valid = false, skipped = false;
    if (i < n) {
+      unsigned long long out = (unsigned long long)light * (unsigned long long)n + (unsigned long long)i;
       Hit h = hits[i];
-      if (h.prim >= 0 && level_ray(primary != 0, cam, g, queue, i, ray)) {
+      F3 lp = mk3(0, 0, 0), fd = mk3(0, 0, 1);
+      float param = -1.0f;
+      if (h.prim >= 0) {
+         Ray ray = load_qray(queue, i);
          F3 P = ray_point(ray, h.t);                                   /* kernel.cu:340 */
          const rt_dev_light &L = sc.lights[light];
-         F3 lp = mk3(L.pos[0], L.pos[1], L.pos[2]);
-         feeler.o = lp; feeler.d = P - lp;                             /* PointLight.h:18-20 */
+         lp = mk3(L.pos[0], L.pos[1], L.pos[2]);
+         fd = P - lp;                                                  /* PointLight.h:18-20 */
+         Ray feeler; feeler.o = lp; feeler.d = fd;
          param = any_intersect(sc, h.prim, feeler);                    /* kernel.cu:351 */
          /* A feeler that misses its own surface (-1) can never be reported shadowed:
           * isFloatLessThan(closest, -1) is false for every accepted t.  The reference still
           * walks the tree for it; that walk is skipped here and counted separately. */
-         if (param != -1.0f) active = true;
-         else atomicAdd(&stats[ST_SHADOW_SKIPPED], 1ULL);
+         valid = param != -1.0f;
+         skipped = !valid;
       }
+      store_qray(shadow_queue, out, lp, fd, param, valid ? 1 : 0);
+      if (!valid) flags[out] = 0;
    }
-   int prim; float t;
-   closest_hit<COUNT>(sc, feeler, param, lds_stack + threadIdx.x, RT_BLOCK, active, prim, t, stats, ST_NODE_VISITS_SHADOW);
-   if (i < n) flags[(long long)light * n + i] = (active && less_than(t, param)) ? 1 : 0;   /* kernel.cu:206 */
-   if (active) atomicAdd(&stats[ST_SHADOW_TRACED], 1ULL);
+   stat_count(stats, ST_SHADOW_TRACED, valid);
+   stat_count(stats, ST_SHADOW_SKIPPED, skipped);
 }
 
 /* PhongShader::shade, PhongShader.h:7-25 */
@@ -480,13 +561,13 @@ __device__ __forceinline__ F3 cook_torrance(F3 matColor, float amb, float dif, f
 }
 
 /* shade: shadeObject (kernel.cu:335-382) minus the recursion; spawns the next level's rays */
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene sc, DCamera cam, DGrid g, int primary, const QRay *queue,
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene sc, const QRay *queue,
                                                     const Hit *hits, const unsigned char *flags, long long n,
                                                     int shading, int spawn, ShadeNode *nodes, QRay *next_queue,
                                                     unsigned *next_count, unsigned next_cap, unsigned long long *stats)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-   bool want_refl = false, want_refr = false;
+   bool want_refl = false, want_refr = false, shaded = false;
    Ray reflRay, refrRay;
    reflRay.o = reflRay.d = refrRay.o = refrRay.d = mk3(0, 0, 0);
    ShadeNode out;
@@ -495,7 +576,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene sc, DCamera cam, DGri
    Ray ray;
    if (i < n) {
       Hit h = hits[i];
-      if (h.prim >= 0 && level_ray(primary != 0, cam, g, queue, i, ray)) {
+      if (h.prim >= 0) {
+         ray = load_qray(queue, i);
          F3 P = ray_point(ray, h.t);
          unsigned mat_id = h.prim < sc.n_prims ? sc.prims[h.prim].material : sc.planes[h.prim - sc.n_prims].material;
          const rt_material m = sc.materials[mat_id];
@@ -537,9 +619,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene sc, DCamera cam, DGri
                }
             }
          }
-         atomicAdd(&stats[ST_SHADE_NODES], 1ULL);
+         shaded = true;
       }
    }
+   stat_count(stats, ST_SHADE_NODES, shaded);
    if (spawn) {
       /* wave-aggregated queue allocation: the wave's reflection rays land contiguously, then its refraction rays */
       unsigned long long mR = __ballot(want_refl), mT = __ballot(want_refr);
@@ -553,20 +636,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene sc, DCamera cam, DGri
          if (want_refl) {
             unsigned slot = base + __popcll(mR & below);
             if (slot < next_cap) {
-               QRay q = {reflRay.o.x, reflRay.o.y, reflRay.o.z, 0.0f, reflRay.d.x, reflRay.d.y, reflRay.d.z, 0.0f};
-               next_queue[slot] = q; out.child_refl = (int)slot;
+               store_qray(next_queue, slot, reflRay.o, reflRay.d, -FLT_MAX, 1); out.child_refl = (int)slot;
             }
          }
          if (want_refr) {
             unsigned slot = base + cR + __popcll(mT & below);
             if (slot < next_cap) {
-               QRay q = {refrRay.o.x, refrRay.o.y, refrRay.o.z, 0.0f, refrRay.d.x, refrRay.d.y, refrRay.d.z, 0.0f};
-               next_queue[slot] = q; out.child_refr = (int)slot;
+               store_qray(next_queue, slot, refrRay.o, refrRay.d, -FLT_MAX, 1); out.child_refr = (int)slot;
             }
          }
          if (lane == (unsigned)__ffsll((long long)(mR | mT)) - 1) {
-            atomicAdd(&stats[ST_REFLECT], (unsigned long long)cR);
-            atomicAdd(&stats[ST_REFRACT], (unsigned long long)cT);
+            stat_add(stats, ST_REFLECT, (unsigned long long)cR);
+            stat_add(stats, ST_REFRACT, (unsigned long long)cT);
          }
       }
    }
@@ -693,12 +774,19 @@ struct rt_scene {
    float ms_build_host, ms_upload;
    Arena arena;             /* per-frame queues; grown on demand, reused across frames */
    unsigned *d_counts;      /* queue counters, one per depth level */
+   unsigned long long *d_next;   /* work counters of the persistent traversal launches (one per launch of a batch) */
    unsigned long long *d_stats;
    unsigned *h_counts;      /* pinned */
    unsigned long long *h_stats;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static unsigned long long sum_stat(const unsigned long long *h, int which)
+{
+   unsigned long long t = 0;
+   for (int r = 0; r < RT_STAT_REPL; r++) t += h[which * RT_STAT_REPL + r];
+   return t;
+}
 
 extern "C" int rt_device_count(void)
 {
@@ -714,6 +802,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
    if (s->dev_blob) (void)hipFree(s->dev_blob);
    if (s->arena.base) (void)hipFree(s->arena.base);
    if (s->d_counts) (void)hipFree(s->d_counts);
+   if (s->d_next) (void)hipFree(s->d_next);
    if (s->d_stats) (void)hipFree(s->d_stats);
    if (s->h_counts) (void)hipHostFree(s->h_counts);
    if (s->h_stats) (void)hipHostFree(s->h_stats);
@@ -730,7 +819,7 @@ extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
    memset(&s->host, 0, sizeof s->host);
    memset(&s->d, 0, sizeof s->d);
    s->device = -1; s->flags = 0;
-   s->dev_blob = nullptr; s->dev_bytes = 0; s->d_counts = nullptr; s->d_stats = nullptr; s->h_counts = nullptr; s->h_stats = nullptr;
+   s->dev_blob = nullptr; s->dev_bytes = 0; s->d_counts = nullptr; s->d_next = nullptr; s->d_stats = nullptr; s->h_counts = nullptr; s->h_stats = nullptr;
    s->camera = desc->camera; s->has_camera = desc->has_camera; s->ms_upload = 0;
    auto t0 = std::chrono::steady_clock::now();
    int st = rt_flatten_scene(desc, &s->host);
@@ -753,7 +842,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    if (!s) return RT_ERR_BAD_ARGUMENT;
    memset(&s->host, 0, sizeof s->host);
    s->device = device; s->flags = flags;
-   s->dev_blob = nullptr; s->d_counts = nullptr; s->d_stats = nullptr; s->h_counts = nullptr; s->h_stats = nullptr;
+   s->dev_blob = nullptr; s->d_counts = nullptr; s->d_next = nullptr; s->d_stats = nullptr; s->h_counts = nullptr; s->h_stats = nullptr;
    s->camera = desc->camera; s->has_camera = desc->has_camera;
 
    auto t0 = std::chrono::steady_clock::now();
@@ -788,9 +877,10 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->d.fast_ok = h.bounds_in_range;
 
    if (hipMalloc((void **)&s->d_counts, 64 * sizeof(unsigned)) != hipSuccess ||
-       hipMalloc((void **)&s->d_stats, ST_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+       hipMalloc((void **)&s->d_next, 64 * sizeof(unsigned long long)) != hipSuccess ||
+       hipMalloc((void **)&s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long)) != hipSuccess ||
        hipHostMalloc((void **)&s->h_counts, 64 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
-       hipHostMalloc((void **)&s->h_stats, ST_COUNT * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+       hipHostMalloc((void **)&s->h_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
       rt_set_error("allocation of queue counters failed"); rt_scene_destroy(s); return RT_ERR_HIP;
    }
    e = hipDeviceSynchronize();
@@ -913,6 +1003,47 @@ static long long max_batch_slots()
    return v > 0 ? v : (long long)(1 << 24);
 }
 
+static int trace_lds_bytes(const rt_scene *s, size_t *out)
+{
+   /* the stack holds at most one deferred sibling per internal level */
+   size_t lds_bytes = sizeof(StackEntry) * (size_t)RT_BLOCK * (size_t)(s->host.tree_depth > 0 ? s->host.tree_depth : 1);
+   if (lds_bytes > 160 * 1024) { rt_set_error("BVH depth %d needs %zu bytes of LDS", s->host.tree_depth, lds_bytes); return RT_ERR_TOO_LARGE; }
+   if (lds_bytes > 64 * 1024) {
+      HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_HIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_HIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_FLAG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_FLAG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+   }
+   *out = lds_bytes;
+   return RT_OK;
+}
+
+static int g_trace_blocks = 0;
+
+/* persistent traversal launch: enough blocks to fill the chip a few times over; every wave pulls rays until the queue is dry */
+static void launch_trace(const rt_scene *s, bool flag_out, bool count, const QRay *rays, unsigned long long n, Hit *hits,
+                         unsigned char *flags, unsigned long long *next, size_t lds_bytes, hipStream_t stream)
+{
+   if (g_trace_blocks == 0) {
+      const char *e = getenv("RT_TRACE_BLOCKS");
+      int cus = 256;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+      g_trace_blocks = e && atoi(e) > 0 ? atoi(e) : cus * 8;
+   }
+   unsigned long long want = (n + RT_BLOCK - 1) / RT_BLOCK;
+   unsigned blocks = (unsigned)(want < (unsigned long long)g_trace_blocks ? want : (unsigned long long)g_trace_blocks);
+   if (blocks == 0) return;
+   int base = flag_out ? ST_NODE_VISITS_SHADOW : ST_NODE_VISITS;
+   if (flag_out) {
+      if (count) hipLaunchKernelGGL((k_trace<OUT_FLAG, true>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, rays, n, hits, flags, next, s->d_stats, base);
+      else hipLaunchKernelGGL((k_trace<OUT_FLAG, false>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, rays, n, hits, flags, next, s->d_stats, base);
+   } else {
+      if (count) hipLaunchKernelGGL((k_trace<OUT_HIT, true>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, rays, n, hits, flags, next, s->d_stats, base);
+      else hipLaunchKernelGGL((k_trace<OUT_HIT, false>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, rays, n, hits, flags, next, s->d_stats, base);
+   }
+}
+
 /* The frame driver: body of launch_kernel after scene set-up (kernel.cu:735-760), over the
  * tiles this call selects, in batches of tiles that bound the queue memory. */
 static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, void *out_dev, int *prim_dev,
@@ -952,19 +1083,15 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    const bool count = (s->flags & RT_SCENE_COUNTERS) != 0;
 
    long long per_tile = (long long)g.ts * g.ts;
-   long long tiles_per_batch = max_batch_slots() / per_tile;
+   /* a batch is bounded by its sample slots and by its shadow rays (one 33-byte queue entry per light per node) */
+   long long batch_slots = max_batch_slots();
+   if (L > 0 && batch_slots * L > (1LL << 28)) batch_slots = (1LL << 28) / L;
+   long long tiles_per_batch = batch_slots / per_tile;
    if (tiles_per_batch < 1) tiles_per_batch = 1;
-   /* the stack holds at most one deferred sibling per internal level */
-   size_t lds_bytes = sizeof(StackEntry) * (size_t)RT_BLOCK * (size_t)(s->host.tree_depth > 0 ? s->host.tree_depth : 1);
-   if (lds_bytes > 160 * 1024) { rt_set_error("BVH depth %d needs %zu bytes of LDS", s->host.tree_depth, lds_bytes); return RT_ERR_TOO_LARGE; }
-   if (lds_bytes > 64 * 1024) {
-      HIP_TRY(hipFuncSetAttribute((const void *)k_extend<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_extend<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_shadow<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_shadow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-   }
+   size_t lds_bytes = 0;
+   { int rc = trace_lds_bytes(s, &lds_bytes); if (rc != RT_OK) return rc; }
 
-   HIP_TRY(hipMemsetAsync(s->d_stats, 0, ST_COUNT * sizeof(unsigned long long), stream));
+   HIP_TRY(hipMemsetAsync(s->d_stats, 0, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), stream));
    EventPool ev;
    Timer &t_total = ev.begin(stream, &st.ms_total);
 
@@ -989,6 +1116,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          s->arena = bigger;
          return RT_OK;
       };
+      lv[0].queue = carve(sizeof(QRay) * (size_t)lv[0].n); lv[0].has_queue = true;
       lv[0].hits = carve(sizeof(Hit) * (size_t)lv[0].n);
       lv[0].nodes = carve(sizeof(ShadeNode) * (size_t)lv[0].n);
       lv[0].rgb = carve(sizeof(float) * 3 * (size_t)lv[0].n);
@@ -996,13 +1124,17 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
 #define AT(T, off) ((T *)(s->arena.base + (off)))
 
       HIP_TRY(hipMemsetAsync(s->d_counts, 0, 64 * sizeof(unsigned), stream));
+      HIP_TRY(hipMemsetAsync(s->d_next, 0, 64 * sizeof(unsigned long long), stream));
+      int n_trace = 0;   /* index of the next unused work counter */
 
-      {  /* level 0 extend: primary rays are generated in the kernel, never stored */
+      {  /* level 0: generate the primary rays, then their closest hits */
+         Timer &tg = ev.begin(stream, &st.ms_generate);
+         hipLaunchKernelGGL(k_generate, dim3(grid_for(lv[0].n)), dim3(RT_BLOCK), 0, stream, cam, g, lv[0].n, AT(QRay, lv[0].queue),
+                            AT(Hit, lv[0].hits), s->d_stats);
+         ev.end(tg, stream);
          Timer &tm = ev.begin(stream, &st.ms_extend);
-         if (count) hipLaunchKernelGGL(k_extend<true>, dim3(grid_for(lv[0].n)), dim3(RT_BLOCK), lds_bytes, stream, sc, cam, g, 1,
-                                       (const QRay *)nullptr, (const float *)nullptr, lv[0].n, AT(Hit, lv[0].hits), s->d_stats);
-         else hipLaunchKernelGGL(k_extend<false>, dim3(grid_for(lv[0].n)), dim3(RT_BLOCK), lds_bytes, stream, sc, cam, g, 1,
-                                 (const QRay *)nullptr, (const float *)nullptr, lv[0].n, AT(Hit, lv[0].hits), s->d_stats);
+         launch_trace(s, false, count, AT(QRay, lv[0].queue), (unsigned long long)lv[0].n, AT(Hit, lv[0].hits), nullptr,
+                      s->d_next + n_trace++, lds_bytes, stream);
          ev.end(tm, stream); st.launches_extend++;
       }
 
@@ -1021,23 +1153,28 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
                next_cap = (unsigned)cap;
                nextq_off = carve(sizeof(QRay) * (size_t)next_cap);
             }
-            /* shadow flags of this level live past the queue: dropped as soon as the level is shaded */
-            size_t flags_off = carve((size_t)(L > 0 ? L : 1) * (size_t)n);
+            /* shadow flags and the shadow-ray queue of this level live past the next queue: dropped as soon as
+             * the level is shaded */
+            unsigned long long n_shadow = (unsigned long long)(L > 0 ? L : 0) * (unsigned long long)n;
+            size_t flags_off = carve((size_t)(n_shadow ? n_shadow : 1));
+            size_t shq_off = carve(sizeof(QRay) * (size_t)(n_shadow ? n_shadow : 1));
             { int rc = grow(live); if (rc != RT_OK) return rc; }
-            const QRay *queue = lv[l].has_queue ? AT(QRay, lv[l].queue) : nullptr;
+            const QRay *queue = AT(QRay, lv[l].queue);
 
             if (L > 0 && n > 0) {
-               Timer &tm = ev.begin(stream, &st.ms_shadow);
+               Timer &ts = ev.begin(stream, &st.ms_shadow_setup);
                dim3 grid(grid_for(n), (unsigned)L);
-               if (count) hipLaunchKernelGGL(k_shadow<true>, grid, dim3(RT_BLOCK), lds_bytes, stream, sc, cam, g, l == 0 ? 1 : 0,
-                                             queue, (const Hit *)AT(Hit, lv[l].hits), n, AT(unsigned char, flags_off), s->d_stats);
-               else hipLaunchKernelGGL(k_shadow<false>, grid, dim3(RT_BLOCK), lds_bytes, stream, sc, cam, g, l == 0 ? 1 : 0,
-                                       queue, (const Hit *)AT(Hit, lv[l].hits), n, AT(unsigned char, flags_off), s->d_stats);
+               hipLaunchKernelGGL(k_shadow_setup, grid, dim3(RT_BLOCK), 0, stream, sc, queue, (const Hit *)AT(Hit, lv[l].hits), n,
+                                  AT(QRay, shq_off), AT(unsigned char, flags_off), s->d_stats);
+               ev.end(ts, stream);
+               Timer &tm = ev.begin(stream, &st.ms_shadow);
+               launch_trace(s, true, count, AT(QRay, shq_off), n_shadow, nullptr, AT(unsigned char, flags_off),
+                            s->d_next + n_trace++, lds_bytes, stream);
                ev.end(tm, stream); st.launches_shadow++;
             }
             {
                Timer &tm = ev.begin(stream, &st.ms_shade);
-               hipLaunchKernelGGL(k_shade, dim3(grid_for(n)), dim3(RT_BLOCK), 0, stream, sc, cam, g, l == 0 ? 1 : 0,
+               hipLaunchKernelGGL(k_shade, dim3(grid_for(n)), dim3(RT_BLOCK), 0, stream, sc,
                                   queue, (const Hit *)AT(Hit, lv[l].hits), (const unsigned char *)AT(unsigned char, flags_off), n,
                                   p->shading, spawn, AT(ShadeNode, lv[l].nodes), spawn ? AT(QRay, nextq_off) : (QRay *)nullptr,
                                   s->d_counts + (l + 1), next_cap, s->d_stats);
@@ -1060,10 +1197,8 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             { int rc = grow(live); if (rc != RT_OK) return rc; }
             {
                Timer &tm = ev.begin(stream, &st.ms_extend);
-               if (count) hipLaunchKernelGGL(k_extend<true>, dim3(grid_for(n_next)), dim3(RT_BLOCK), lds_bytes, stream, sc, cam, g, 0,
-                                             (const QRay *)AT(QRay, lv[l + 1].queue), (const float *)nullptr, n_next, AT(Hit, lv[l + 1].hits), s->d_stats);
-               else hipLaunchKernelGGL(k_extend<false>, dim3(grid_for(n_next)), dim3(RT_BLOCK), lds_bytes, stream, sc, cam, g, 0,
-                                       (const QRay *)AT(QRay, lv[l + 1].queue), (const float *)nullptr, n_next, AT(Hit, lv[l + 1].hits), s->d_stats);
+               launch_trace(s, false, count, AT(QRay, lv[l + 1].queue), (unsigned long long)n_next, AT(Hit, lv[l + 1].hits), nullptr,
+                            s->d_next + n_trace++, lds_bytes, stream);
                ev.end(tm, stream); st.launches_extend++;
             }
          }
@@ -1094,23 +1229,23 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       HIP_TRY(hipGetLastError());
    }
    ev.end(t_total, stream);
-   HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, ST_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+   HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
    HIP_TRY(hipStreamSynchronize(stream));
    HIP_TRY(hipGetLastError());
    ev.collect();
-   st.rays_primary = s->h_stats[ST_PRIMARY];
-   st.rays_shadow = s->h_stats[ST_SHADOW_TRACED];
-   st.shadow_skipped = s->h_stats[ST_SHADOW_SKIPPED];
-   st.rays_reflect = s->h_stats[ST_REFLECT];
-   st.rays_refract = s->h_stats[ST_REFRACT];
-   st.shade_nodes = s->h_stats[ST_SHADE_NODES];
+   st.rays_primary = sum_stat(s->h_stats, ST_PRIMARY);
+   st.rays_shadow = sum_stat(s->h_stats, ST_SHADOW_TRACED);
+   st.shadow_skipped = sum_stat(s->h_stats, ST_SHADOW_SKIPPED);
+   st.rays_reflect = sum_stat(s->h_stats, ST_REFLECT);
+   st.rays_refract = sum_stat(s->h_stats, ST_REFRACT);
+   st.shade_nodes = sum_stat(s->h_stats, ST_SHADE_NODES);
    st.rays_total = st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract;
    st.samples = st.rays_primary;
-   st.node_visits = s->h_stats[ST_NODE_VISITS]; st.prim_tests = s->h_stats[ST_PRIM_TESTS]; st.tie_events = s->h_stats[ST_TIES];
-   st.node_visits_shadow = s->h_stats[ST_NODE_VISITS_SHADOW]; st.prim_tests_shadow = s->h_stats[ST_PRIM_TESTS_SHADOW];
-   st.tie_events_shadow = s->h_stats[ST_TIES_SHADOW];
-   st.wave_node_steps = s->h_stats[ST_WAVE_NODE_STEPS]; st.wave_leaf_steps = s->h_stats[ST_WAVE_LEAF_STEPS];
-   st.wave_node_steps_shadow = s->h_stats[ST_WAVE_NODE_STEPS_SHADOW]; st.wave_leaf_steps_shadow = s->h_stats[ST_WAVE_LEAF_STEPS_SHADOW];
+   st.node_visits = sum_stat(s->h_stats, ST_NODE_VISITS); st.prim_tests = sum_stat(s->h_stats, ST_PRIM_TESTS); st.tie_events = sum_stat(s->h_stats, ST_TIES);
+   st.node_visits_shadow = sum_stat(s->h_stats, ST_NODE_VISITS_SHADOW); st.prim_tests_shadow = sum_stat(s->h_stats, ST_PRIM_TESTS_SHADOW);
+   st.tie_events_shadow = sum_stat(s->h_stats, ST_TIES_SHADOW);
+   st.wave_node_steps = sum_stat(s->h_stats, ST_WAVE_NODE_STEPS); st.wave_leaf_steps = sum_stat(s->h_stats, ST_WAVE_LEAF_STEPS);
+   st.wave_node_steps_shadow = sum_stat(s->h_stats, ST_WAVE_NODE_STEPS_SHADOW); st.wave_leaf_steps_shadow = sum_stat(s->h_stats, ST_WAVE_LEAF_STEPS_SHADOW);
    if (stats_out) *stats_out = st;
    return RT_OK;
 }
@@ -1203,29 +1338,22 @@ extern "C" int rt_trace_rays(const rt_scene *cs, int64_t n, const float *rays_ho
    std::vector<QRay> q((size_t)n);
    for (int64_t i = 0; i < n; i++) {
       const float *r = rays_host + 6 * i;
-      QRay e = {r[0], r[1], r[2], 0.0f, r[3], r[4], r[5], 0.0f};
+      QRay e = {r[0], r[1], r[2], to_beat_host ? to_beat_host[i] : -FLT_MAX, r[3], r[4], r[5], 1};
       q[(size_t)i] = e;
    }
-   QRay *d_q = nullptr; Hit *d_h = nullptr; float *d_tb = nullptr;
+   QRay *d_q = nullptr; Hit *d_h = nullptr;
    int rc = RT_OK;
-   size_t lds_bytes = sizeof(StackEntry) * (size_t)RT_BLOCK * (size_t)(s->host.tree_depth > 0 ? s->host.tree_depth : 1);
-   if (lds_bytes > 160 * 1024) { rt_set_error("BVH too deep for the LDS stack"); return RT_ERR_TOO_LARGE; }
-   if (lds_bytes > 64 * 1024) {
-      HIP_TRY(hipFuncSetAttribute((const void *)k_extend<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_extend<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-   }
-   if (hipMalloc((void **)&d_q, sizeof(QRay) * (size_t)n) != hipSuccess || hipMalloc((void **)&d_h, sizeof(Hit) * (size_t)n) != hipSuccess ||
-       (to_beat_host && hipMalloc((void **)&d_tb, 4 * (size_t)n) != hipSuccess)) {
+   size_t lds_bytes = 0;
+   rc = trace_lds_bytes(s, &lds_bytes);
+   if (rc != RT_OK) return rc;
+   if (hipMalloc((void **)&d_q, sizeof(QRay) * (size_t)n) != hipSuccess || hipMalloc((void **)&d_h, sizeof(Hit) * (size_t)n) != hipSuccess) {
       rt_set_error("rt_trace_rays: hipMalloc failed"); rc = RT_ERR_HIP;
    }
    if (rc == RT_OK) {
       (void)hipMemcpy(d_q, q.data(), sizeof(QRay) * (size_t)n, hipMemcpyHostToDevice);
-      if (d_tb) (void)hipMemcpy(d_tb, to_beat_host, 4 * (size_t)n, hipMemcpyHostToDevice);
-      (void)hipMemset(s->d_stats, 0, ST_COUNT * sizeof(unsigned long long));
-      DGrid g; memset(&g, 0, sizeof g);
-      DCamera cam; memset(&cam, 0, sizeof cam);
-      hipLaunchKernelGGL(k_extend<false>, dim3(grid_for(n)), dim3(RT_BLOCK), lds_bytes, 0, s->d, cam, g, 0, (const QRay *)d_q,
-                         (const float *)d_tb, (long long)n, d_h, s->d_stats);
+      (void)hipMemset(s->d_stats, 0, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long));
+      (void)hipMemset(s->d_next, 0, sizeof(unsigned long long));
+      launch_trace(s, false, false, d_q, (unsigned long long)n, d_h, nullptr, s->d_next, lds_bytes, 0);
       std::vector<Hit> h((size_t)n);
       hipError_t e = hipMemcpy(h.data(), d_h, sizeof(Hit) * (size_t)n, hipMemcpyDeviceToHost);
       if (e != hipSuccess) { rt_set_error("rt_trace_rays: %s", hipGetErrorString(e)); rc = RT_ERR_HIP; }
@@ -1233,6 +1361,5 @@ extern "C" int rt_trace_rays(const rt_scene *cs, int64_t n, const float *rays_ho
    }
    if (d_q) (void)hipFree(d_q);
    if (d_h) (void)hipFree(d_h);
-   if (d_tb) (void)hipFree(d_tb);
    return rc;
 }
