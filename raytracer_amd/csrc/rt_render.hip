@@ -246,7 +246,7 @@ extern __shared__ StackEntry lds_stack[];
 enum { OUT_HIT = 0, OUT_FLAG = 1 };
 
 #define RT_REFILL_IDLE 20   /* pull new rays once this many lanes of the wave are idle */
-#define RT_LEAF_WAIT 12     /* run a primitive step once this many lanes wait at a leaf */
+#define RT_NODE_BURST 6     /* node steps between two leaf steps / refill checks */
 
 __device__ __forceinline__ QRay load_qray_rec(const QRay *q, unsigned long long i)
 {
@@ -269,19 +269,54 @@ __device__ __forceinline__ Ray load_qray(const QRay *q, long long i)
    return r;
 }
 
+/* one primitive test of the traversal (kernel.cu:104-134): returns true when the ray is done early */
+__device__ __forceinline__ bool leaf_test(const DScene &sc, const Ray &ray, int prim, float toBeat, float &t, int &closest,
+                                          unsigned &n_ties)
+{
+   float dist = prim_intersect(sc, prim, ray);
+   bool take = false;
+   if (is_equal(t, dist)) {
+      n_ties++;
+      if (closest >= 0)
+         take = tie_prefers_new(sc.prims, sc.xforms, sc.shades, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z,
+                                closest, t, prim, dist);
+   } else {
+      take = dist < t && above_zero(dist);
+   }
+   if (take) {
+      t = dist; closest = prim;
+      return t < toBeat;                                 /* kernel.cu:117-121, 128-132 */
+   }
+   return false;
+}
+
+/* planes after the tree: kernel.cu:189-196 (no tie rule, no toBeat exit) */
+__device__ __forceinline__ void plane_scan(const DScene &sc, const Ray &ray, float &t, int &closest)
+{
+   for (int k = 0; k < sc.n_planes; k++) {
+      float dist = plane_intersect(sc, k, ray);
+      if (less_than(dist, t) && above_zero(dist)) { closest = sc.n_prims + k; t = dist; }
+   }
+}
+
 /* k_trace: persistent-thread closest-hit / any-hit over a ray queue.
  *
  * Lane state is one ray: (ctx, t, closest, cur, sp).  cur >= 0 is an internal node, cur < 0 a leaf
- * (~cur = primitive).  The wave alternates between
+ * (~cur = primitive).  The wave alternates between bursts of
  *   node steps  -- every lane at an internal node tests the two child boxes of its node
  *                  (kernel.cu:136-158) and descends / defers / pops,
- *   leaf steps  -- every lane at a leaf intersects its primitive (kernel.cu:104-134) and pops,
- * running a leaf step only when RT_LEAF_WAIT lanes are waiting for one (or nothing else can run), and
- * refills idle lanes from the queue when RT_REFILL_IDLE of them are free.  A ray's own sequence of
- * operations is exactly that of the reference loop; only the interleaving between rays differs. */
+ * and one
+ *   leaf step   -- every lane at a leaf intersects its primitive (kernel.cu:104-134) and pops,
+ * and refills idle lanes from the queue when RT_REFILL_IDLE of them are free.  A ray's own sequence
+ * of operations is exactly that of the reference loop; only the interleaving between rays differs.
+ *
+ * Only rays the short box test is exact for run here (no axis-parallel direction, values in range:
+ * RayCtx::fast).  The others -- typically the one pixel column or row whose direction has an exact
+ * zero -- are appended to `slow_list` and traced by k_trace_slow with the literal arithmetic. */
 template <int OUT, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays, unsigned long long n, Hit *hits,
                                                     unsigned char *flags, unsigned long long *next,
+                                                    unsigned *slow_list, unsigned *slow_count,
                                                     unsigned long long *stats, int stat_base)
 {
    StackEntry *stack = lds_stack + threadIdx.x;
@@ -295,17 +330,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
    c.r.o = mk3(0, 0, 0); c.r.d = mk3(1, 1, 1); c.yx = c.yy = c.yz = 1.0f; c.fast = true;
    float t = FLT_MAX, toBeat = -FLT_MAX;
    int closest = -1, cur = 0, sp = 0;
-   unsigned long long idx = 0;
+   unsigned idx = 0;
    unsigned nv = 0, np = 0, nt = 0, wn = 0, wl = 0;
 
-   /* a ray is finished: scan the planes unless it left early (kernel.cu:189-196), write its result */
+   /* a ray is finished: scan the planes unless it left early, write its result */
    auto finish = [&](bool early) {
-      if (!early) {
-         for (int k = 0; k < sc.n_planes; k++) {
-            float dist = plane_intersect(sc, k, c.r);
-            if (less_than(dist, t) && above_zero(dist)) { closest = sc.n_prims + k; t = dist; }
-         }
-      }
+      if (!early) plane_scan(sc, c.r, t, closest);
       if (OUT == OUT_HIT) { Hit h; h.prim = closest; h.t = t; hits[idx] = h; }
       else flags[idx] = less_than(t, toBeat) ? 1 : 0;            /* kernel.cu:206 */
       active = false;
@@ -338,10 +368,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
                if (q.valid) {
                   Ray r; r.o = mk3(q.ox, q.oy, q.oz); r.d = mk3(q.dx, q.dy, q.dz);
                   c = make_ctx(r);
-                  toBeat = q.to_beat; idx = my;
-                  t = FLT_MAX; closest = -1; sp = 0; cur = sc.root;
-                  active = true;
-                  if (cur == RT_ROOT_EMPTY) finish(false);
+                  if (c.fast && sc.fast_ok) {
+                     toBeat = q.to_beat; idx = (unsigned)my;
+                     t = FLT_MAX; closest = -1; sp = 0; cur = sc.root;
+                     active = true;
+                     if (cur == RT_ROOT_EMPTY) finish(false);
+                  } else {
+                     slow_list[atomicAdd(slow_count, 1u)] = (unsigned)my;
+                  }
                }
             }
          }
@@ -351,28 +385,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
          if (exhausted) break;
          continue;
       }
-      bool at_leaf = active && cur < 0;
-      unsigned long long mL = __ballot(at_leaf);
-      unsigned long long mI = m_active & ~mL;
-      if (mI != 0 && __popcll(mL) < RT_LEAF_WAIT) {
-         /* ---- node step ---- */
+      /* ---- node steps ---- */
+#pragma unroll 1
+      for (int burst = 0; burst < RT_NODE_BURST; burst++) {
          bool in_node = active && cur >= 0;
-         /* both box-test forms give the same bits; the literal one also covers parallel axes and
-          * out-of-range values, so the wave takes it whenever one of its lanes needs it */
-         bool wave_fast = sc.fast_ok && __ballot(in_node && !c.fast) == 0;
+         if (__ballot(in_node) == 0) break;
          if (COUNT) wn++;
          if (in_node) {
             float4 a, b, cc, d;
             load_node(sc.nodes, cur, a, b, cc, d);
             if (COUNT) nv++;
-            float left, right;
-            if (wave_fast) {
-               left = slab_fast(c, a.x, a.y, a.z, a.w, b.x, b.y);
-               right = slab_fast(c, b.z, b.w, cc.x, cc.y, cc.z, cc.w);
-            } else {
-               left = slab_literal(c.r, a.x, a.y, a.z, a.w, b.x, b.y);
-               right = slab_literal(c.r, b.z, b.w, cc.x, cc.y, cc.z, cc.w);
-            }
+            float left = slab_fast(c, a.x, a.y, a.z, a.w, b.x, b.y);
+            float right = slab_fast(c, b.z, b.w, cc.x, cc.y, cc.z, cc.w);
             int li = __float_as_int(d.x), ri = __float_as_int(d.y);
             bool aL = above_zero(left), aR = above_zero(right);
             if (aR && (right <= left || !aL) && right < t) {
@@ -385,28 +409,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
                pop();
             }
          }
-      } else {
-         /* ---- leaf step ---- */
+      }
+      /* ---- leaf step ---- */
+      bool at_leaf = active && cur < 0;
+      if (__ballot(at_leaf) != 0) {
          if (COUNT) wl++;
          if (at_leaf) {
-            int prim = ~cur;
             if (COUNT) np++;
-            float dist = prim_intersect(sc, prim, c.r);
-            bool take = false;
-            if (is_equal(t, dist)) {
-               if (COUNT) nt++;
-               if (closest >= 0)
-                  take = tie_prefers_new(sc.prims, sc.xforms, sc.shades, c.r.o.x, c.r.o.y, c.r.o.z, c.r.d.x, c.r.d.y, c.r.d.z,
-                                         closest, t, prim, dist);
-            } else {
-               take = dist < t && above_zero(dist);
-            }
-            bool early = false;
-            if (take) {
-               t = dist; closest = prim;
-               early = t < toBeat;                       /* kernel.cu:117-121, 128-132 */
-            }
-            if (early) finish(true);
+            if (leaf_test(sc, c.r, ~cur, toBeat, t, closest, nt)) finish(true);
             else pop();
          }
       }
@@ -419,6 +429,67 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
          stat_add(stats, stat_base + 3, (unsigned long long)wn);
          stat_add(stats, stat_base + 4, (unsigned long long)wl);
       }
+   }
+}
+
+/* k_trace_slow: the same query with the reference's literal box test (true divisions, parallel-axis
+ * branches), one ray per thread, for the rays k_trace set aside.  Grid-stride over the device-side count. */
+template <int OUT, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_slow(DScene sc, const QRay *rays, Hit *hits, unsigned char *flags,
+                                                         const unsigned *slow_list, const unsigned *slow_count,
+                                                         unsigned long long *stats, int stat_base)
+{
+   StackEntry *stack = lds_stack + threadIdx.x;
+   const int stride = RT_BLOCK;
+   unsigned total = *slow_count;
+   unsigned nv = 0, np = 0, nt = 0;
+   for (unsigned k = blockIdx.x * RT_BLOCK + threadIdx.x; k < total; k += gridDim.x * RT_BLOCK) {
+      unsigned idx = slow_list[k];
+      QRay q = load_qray_rec(rays, idx);
+      Ray ray; ray.o = mk3(q.ox, q.oy, q.oz); ray.d = mk3(q.dx, q.dy, q.dz);
+      float toBeat = q.to_beat, t = FLT_MAX;
+      int closest = -1, cur = sc.root, sp = 0;
+      bool done = (cur == RT_ROOT_EMPTY), early = false;
+      while (!done) {
+         bool need_pop = false;
+         if (cur >= 0) {
+            float4 a, b, cc, d;
+            load_node(sc.nodes, cur, a, b, cc, d);
+            if (COUNT) nv++;
+            float left = slab_literal(ray, a.x, a.y, a.z, a.w, b.x, b.y);
+            float right = slab_literal(ray, b.z, b.w, cc.x, cc.y, cc.z, cc.w);
+            int li = __float_as_int(d.x), ri = __float_as_int(d.y);
+            bool aL = above_zero(left), aR = above_zero(right);
+            if (aR && (right <= left || !aL) && right < t) {
+               if (aL) { StackEntry e; e.child = li; e.dist = left; stack[sp * stride] = e; sp++; }
+               cur = ri;
+            } else if (aL && (left <= right || !aR) && left < t) {
+               if (aR) { StackEntry e; e.child = ri; e.dist = right; stack[sp * stride] = e; sp++; }
+               cur = li;
+            } else need_pop = true;
+         } else {
+            if (COUNT) np++;
+            if (leaf_test(sc, ray, ~cur, toBeat, t, closest, nt)) { early = true; done = true; }
+            else need_pop = true;
+         }
+         if (need_pop) {
+            bool found = false;
+            while (sp > 0) {
+               sp--;
+               StackEntry e = stack[sp * stride];
+               if (e.dist < t) { cur = e.child; found = true; break; }
+            }
+            if (!found) done = true;
+         }
+      }
+      if (!early) plane_scan(sc, ray, t, closest);
+      if (OUT == OUT_HIT) { Hit h; h.prim = closest; h.t = t; hits[idx] = h; }
+      else flags[idx] = less_than(t, toBeat) ? 1 : 0;
+   }
+   if (COUNT) {
+      stat_add(stats, stat_base + 0, (unsigned long long)nv);
+      stat_add(stats, stat_base + 1, (unsigned long long)np);
+      stat_add(stats, stat_base + 2, (unsigned long long)nt);
    }
 }
 
@@ -959,6 +1030,7 @@ struct LevelBufs {
    size_t hits = 0;       /* Hit[n] */
    size_t nodes = 0;      /* ShadeNode[n] */
    size_t rgb = 0;        /* float[3n] */
+   size_t slow = 0;       /* unsigned[n]: rays set aside for the literal-arithmetic kernel */
    bool has_queue = false;
 };
 
@@ -1013,6 +1085,10 @@ static int trace_lds_bytes(const rt_scene *s, size_t *out)
       HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_HIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_FLAG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_FLAG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_trace_slow<OUT_HIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_trace_slow<OUT_HIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_trace_slow<OUT_FLAG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_trace_slow<OUT_FLAG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
    }
    *out = lds_bytes;
    return RT_OK;
@@ -1020,9 +1096,12 @@ static int trace_lds_bytes(const rt_scene *s, size_t *out)
 
 static int g_trace_blocks = 0;
 
-/* persistent traversal launch: enough blocks to fill the chip a few times over; every wave pulls rays until the queue is dry */
+/* persistent traversal launch: enough blocks to fill the chip a few times over; every wave pulls rays until
+ * the queue is dry.  `next` is this launch's zeroed work counter, next[1] (as unsigned) the slow-ray count;
+ * slow_list has room for n indices. */
 static void launch_trace(const rt_scene *s, bool flag_out, bool count, const QRay *rays, unsigned long long n, Hit *hits,
-                         unsigned char *flags, unsigned long long *next, size_t lds_bytes, hipStream_t stream)
+                         unsigned char *flags, unsigned long long *next, unsigned *slow_list, size_t lds_bytes,
+                         hipStream_t stream)
 {
    if (g_trace_blocks == 0) {
       const char *e = getenv("RT_TRACE_BLOCKS");
@@ -1034,14 +1113,19 @@ static void launch_trace(const rt_scene *s, bool flag_out, bool count, const QRa
    unsigned long long want = (n + RT_BLOCK - 1) / RT_BLOCK;
    unsigned blocks = (unsigned)(want < (unsigned long long)g_trace_blocks ? want : (unsigned long long)g_trace_blocks);
    if (blocks == 0) return;
+   unsigned slow_blocks = blocks < 128 ? blocks : 128;
    int base = flag_out ? ST_NODE_VISITS_SHADOW : ST_NODE_VISITS;
-   if (flag_out) {
-      if (count) hipLaunchKernelGGL((k_trace<OUT_FLAG, true>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, rays, n, hits, flags, next, s->d_stats, base);
-      else hipLaunchKernelGGL((k_trace<OUT_FLAG, false>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, rays, n, hits, flags, next, s->d_stats, base);
-   } else {
-      if (count) hipLaunchKernelGGL((k_trace<OUT_HIT, true>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, rays, n, hits, flags, next, s->d_stats, base);
-      else hipLaunchKernelGGL((k_trace<OUT_HIT, false>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, rays, n, hits, flags, next, s->d_stats, base);
-   }
+   unsigned *slow_count = reinterpret_cast<unsigned *>(next + 1);
+#define RT_LAUNCH_TRACE(O, C)                                                                                                      \
+   do {                                                                                                                            \
+      hipLaunchKernelGGL((k_trace<O, C>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, rays, n, hits, flags, next,       \
+                         slow_list, slow_count, s->d_stats, base);                                                                 \
+      hipLaunchKernelGGL((k_trace_slow<O, C>), dim3(slow_blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, rays, hits, flags,      \
+                         (const unsigned *)slow_list, (const unsigned *)slow_count, s->d_stats, base);                             \
+   } while (0)
+   if (flag_out) { if (count) RT_LAUNCH_TRACE(OUT_FLAG, true); else RT_LAUNCH_TRACE(OUT_FLAG, false); }
+   else { if (count) RT_LAUNCH_TRACE(OUT_HIT, true); else RT_LAUNCH_TRACE(OUT_HIT, false); }
+#undef RT_LAUNCH_TRACE
 }
 
 /* The frame driver: body of launch_kernel after scene set-up (kernel.cu:735-760), over the
@@ -1120,6 +1204,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       lv[0].hits = carve(sizeof(Hit) * (size_t)lv[0].n);
       lv[0].nodes = carve(sizeof(ShadeNode) * (size_t)lv[0].n);
       lv[0].rgb = carve(sizeof(float) * 3 * (size_t)lv[0].n);
+      lv[0].slow = carve(sizeof(unsigned) * (size_t)lv[0].n);
       { int rc = grow(0); if (rc != RT_OK) return rc; }
 #define AT(T, off) ((T *)(s->arena.base + (off)))
 
@@ -1134,7 +1219,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          ev.end(tg, stream);
          Timer &tm = ev.begin(stream, &st.ms_extend);
          launch_trace(s, false, count, AT(QRay, lv[0].queue), (unsigned long long)lv[0].n, AT(Hit, lv[0].hits), nullptr,
-                      s->d_next + n_trace++, lds_bytes, stream);
+                      s->d_next + 2 * n_trace++, AT(unsigned, lv[0].slow), lds_bytes, stream);
          ev.end(tm, stream); st.launches_extend++;
       }
 
@@ -1158,6 +1243,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             unsigned long long n_shadow = (unsigned long long)(L > 0 ? L : 0) * (unsigned long long)n;
             size_t flags_off = carve((size_t)(n_shadow ? n_shadow : 1));
             size_t shq_off = carve(sizeof(QRay) * (size_t)(n_shadow ? n_shadow : 1));
+            size_t shslow_off = carve(sizeof(unsigned) * (size_t)(n_shadow ? n_shadow : 1));
             { int rc = grow(live); if (rc != RT_OK) return rc; }
             const QRay *queue = AT(QRay, lv[l].queue);
 
@@ -1169,7 +1255,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
                ev.end(ts, stream);
                Timer &tm = ev.begin(stream, &st.ms_shadow);
                launch_trace(s, true, count, AT(QRay, shq_off), n_shadow, nullptr, AT(unsigned char, flags_off),
-                            s->d_next + n_trace++, lds_bytes, stream);
+                            s->d_next + 2 * n_trace++, AT(unsigned, shslow_off), lds_bytes, stream);
                ev.end(tm, stream); st.launches_shadow++;
             }
             {
@@ -1194,11 +1280,12 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             lv[l + 1].hits = carve(sizeof(Hit) * (size_t)n_next);
             lv[l + 1].nodes = carve(sizeof(ShadeNode) * (size_t)n_next);
             lv[l + 1].rgb = carve(sizeof(float) * 3 * (size_t)n_next);
+            lv[l + 1].slow = carve(sizeof(unsigned) * (size_t)n_next);
             { int rc = grow(live); if (rc != RT_OK) return rc; }
             {
                Timer &tm = ev.begin(stream, &st.ms_extend);
                launch_trace(s, false, count, AT(QRay, lv[l + 1].queue), (unsigned long long)n_next, AT(Hit, lv[l + 1].hits), nullptr,
-                            s->d_next + n_trace++, lds_bytes, stream);
+                            s->d_next + 2 * n_trace++, AT(unsigned, lv[l + 1].slow), lds_bytes, stream);
                ev.end(tm, stream); st.launches_extend++;
             }
          }
@@ -1341,19 +1428,20 @@ extern "C" int rt_trace_rays(const rt_scene *cs, int64_t n, const float *rays_ho
       QRay e = {r[0], r[1], r[2], to_beat_host ? to_beat_host[i] : -FLT_MAX, r[3], r[4], r[5], 1};
       q[(size_t)i] = e;
    }
-   QRay *d_q = nullptr; Hit *d_h = nullptr;
+   QRay *d_q = nullptr; Hit *d_h = nullptr; unsigned *d_slow = nullptr;
    int rc = RT_OK;
    size_t lds_bytes = 0;
    rc = trace_lds_bytes(s, &lds_bytes);
    if (rc != RT_OK) return rc;
-   if (hipMalloc((void **)&d_q, sizeof(QRay) * (size_t)n) != hipSuccess || hipMalloc((void **)&d_h, sizeof(Hit) * (size_t)n) != hipSuccess) {
+   if (hipMalloc((void **)&d_q, sizeof(QRay) * (size_t)n) != hipSuccess || hipMalloc((void **)&d_h, sizeof(Hit) * (size_t)n) != hipSuccess ||
+       hipMalloc((void **)&d_slow, sizeof(unsigned) * (size_t)n) != hipSuccess) {
       rt_set_error("rt_trace_rays: hipMalloc failed"); rc = RT_ERR_HIP;
    }
    if (rc == RT_OK) {
       (void)hipMemcpy(d_q, q.data(), sizeof(QRay) * (size_t)n, hipMemcpyHostToDevice);
       (void)hipMemset(s->d_stats, 0, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long));
-      (void)hipMemset(s->d_next, 0, sizeof(unsigned long long));
-      launch_trace(s, false, false, d_q, (unsigned long long)n, d_h, nullptr, s->d_next, lds_bytes, 0);
+      (void)hipMemset(s->d_next, 0, 2 * sizeof(unsigned long long));
+      launch_trace(s, false, false, d_q, (unsigned long long)n, d_h, nullptr, s->d_next, d_slow, lds_bytes, 0);
       std::vector<Hit> h((size_t)n);
       hipError_t e = hipMemcpy(h.data(), d_h, sizeof(Hit) * (size_t)n, hipMemcpyDeviceToHost);
       if (e != hipSuccess) { rt_set_error("rt_trace_rays: %s", hipGetErrorString(e)); rc = RT_ERR_HIP; }
@@ -1361,5 +1449,6 @@ extern "C" int rt_trace_rays(const rt_scene *cs, int64_t n, const float *rays_ho
    }
    if (d_q) (void)hipFree(d_q);
    if (d_h) (void)hipFree(d_h);
+   if (d_slow) (void)hipFree(d_slow);
    return rc;
 }
