@@ -129,10 +129,11 @@ typedef struct rt_stats {
    uint64_t shadow_skipped;     /* shadow feelers whose self-test missed: the reference still walks the tree for them, the outcome is always "lit" */
    uint64_t shade_nodes;        /* shadeObject invocations */
    uint64_t samples;
-   /* device time, ms (HIP events on the render stream) */
-   float ms_total;              /* first extend launch -> resolve completion */
+   /* device time, ms (HIP events).  ms_total spans the frame on the caller's stream; the per-kernel sums
+    * are taken on the library's two internal streams, which overlap, so they can add up to more than it */
+   float ms_total;              /* first launch -> resolve completion */
    float ms_extend, ms_shadow, ms_shade, ms_combine, ms_resolve;   /* extend / shadow: the traversal launches alone */
-   float ms_generate, ms_shadow_setup;
+   float ms_generate, ms_shadow_setup, ms_light;   /* ms_shade: the spawn half of shading; ms_light: the light sums */
    int32_t launches_extend, launches_shadow;
    /* traversal work counters (only filled when the scene was created with RT_SCENE_COUNTERS):
     * 64-byte node records fetched, primitive records tested, near-tie events -- for the

@@ -81,18 +81,17 @@ struct Hit { int prim; float t; };
 /* queue entry, 32 bytes: origin, early-out threshold (toBeat, kernel.cu:84), direction, valid flag */
 struct QRay { float ox, oy, oz, to_beat, dx, dy, dz; int valid; };
 
-/* result of shading one node: the operands of kernel.cu:375-376 */
-struct ShadeNode {
-   float total[3];
+/* what a shade node hands to the combine step besides its light sum: the weights and the
+ * children of kernel.cu:375-376 */
+struct SpawnRec {
    float refl, alpha;
    int child_refl, child_refr;   /* index into the next level, -1 = no ray */
-   int pad;
 };
 
 enum { ST_SHADOW_TRACED = 0, ST_SHADOW_SKIPPED, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES, ST_PRIMARY,
        ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
        ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_WAVE_NODE_STEPS_SHADOW, ST_WAVE_LEAF_STEPS_SHADOW,
-       ST_COUNT };
+       ST_ABORTED, ST_COUNT };
 
 /* Statistics counters are replicated RT_STAT_REPL times (blocks spread over the replicas, the host
  * sums them) and bumped once per wave, so that counting does not serialise the kernels on one word. */
@@ -245,6 +244,7 @@ extern __shared__ StackEntry lds_stack[];
 
 enum { OUT_HIT = 0, OUT_FLAG = 1 };
 
+#define RT_STEP_CAP (1ULL << 28)
 #define RT_REFILL_IDLE 20   /* pull new rays once this many lanes of the wave are idle */
 #define RT_NODE_BURST 6     /* node steps between two leaf steps / refill checks */
 
@@ -351,7 +351,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
       if (!found) finish(false);
    };
 
+   /* Every wave reaches its exit in a bounded number of steps: a ray visits each node at most once per
+    * stack entry, so RT_STEP_CAP is far beyond any real traversal; hitting it means a corrupted scene and
+    * is reported through stats[ST_ABORTED] instead of spinning. */
+   unsigned long long guard = 0;
    for (;;) {
+      if (++guard > RT_STEP_CAP) { if (lane == 0) stat_add(stats, ST_ABORTED, 1ULL); break; }
       unsigned long long m_active = __ballot(active);
       int n_idle = 64 - __popcll(m_active);
       if (!exhausted && n_idle >= RT_REFILL_IDLE) {
@@ -450,7 +455,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_slow(DScene sc, const QRay *
       float toBeat = q.to_beat, t = FLT_MAX;
       int closest = -1, cur = sc.root, sp = 0;
       bool done = (cur == RT_ROOT_EMPTY), early = false;
+      unsigned long long guard = 0;
       while (!done) {
+         if (++guard > RT_STEP_CAP) { stat_add(stats, ST_ABORTED, 1ULL); break; }
          bool need_pop = false;
          if (cur >= 0) {
             float4 a, b, cc, d;
@@ -631,66 +638,64 @@ __device__ __forceinline__ F3 cook_torrance(F3 matColor, float amb, float dif, f
    return light * matColor;
 }
 
-/* shade: shadeObject (kernel.cu:335-382) minus the recursion; spawns the next level's rays */
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene sc, const QRay *queue,
-                                                    const Hit *hits, const unsigned char *flags, long long n,
-                                                    int shading, int spawn, ShadeNode *nodes, QRay *next_queue,
-                                                    unsigned *next_count, unsigned next_cap, unsigned long long *stats)
+/* what both halves of shadeObject (kernel.cu:335-382) need about a hit */
+struct ShadePoint { Ray ray; F3 P, normal, eye; rt_material m; };
+
+__device__ __forceinline__ ShadePoint shade_point(const DScene &sc, const QRay *queue, long long i, Hit h)
+{
+   ShadePoint sp;
+   sp.ray = load_qray(queue, i);
+   sp.P = ray_point(sp.ray, h.t);                               /* kernel.cu:340 */
+   unsigned mat_id = h.prim < sc.n_prims ? sc.prims[h.prim].material : sc.planes[h.prim - sc.n_prims].material;
+   sp.m = sc.materials[mat_id];
+   sp.normal = normal_at(sc, h.prim, sp.ray, h.t);              /* kernel.cu:342 */
+   sp.eye = normalize3(-sp.ray.d);                              /* kernel.cu:344 */
+   return sp;
+}
+
+/* spawn: the reflection / refraction rays of every hit of a level (getReflection / getRefraction,
+ * kernel.cu:209-276, guarded as in kernel.cu:361-371) into the next level's queue.  It needs no shadow
+ * result, so it runs right behind the level's extend while the shadow rays are traced elsewhere. */
+__global__ __launch_bounds__(RT_BLOCK) void k_spawn(DScene sc, const QRay *queue, const Hit *hits, long long n, int spawn,
+                                                    SpawnRec *recs, QRay *next_queue, unsigned *next_count,
+                                                    unsigned next_cap, unsigned long long *stats)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
    bool want_refl = false, want_refr = false, shaded = false;
    Ray reflRay, refrRay;
    reflRay.o = reflRay.d = refrRay.o = refrRay.d = mk3(0, 0, 0);
-   ShadeNode out;
-   out.total[0] = out.total[1] = out.total[2] = 0.0f;
-   out.refl = out.alpha = 0.0f; out.child_refl = out.child_refr = -1; out.pad = 0;
-   Ray ray;
+   SpawnRec out;
+   out.refl = out.alpha = 0.0f; out.child_refl = out.child_refr = -1;
    if (i < n) {
       Hit h = hits[i];
       if (h.prim >= 0) {
-         ray = load_qray(queue, i);
-         F3 P = ray_point(ray, h.t);
+         shaded = true;
          unsigned mat_id = h.prim < sc.n_prims ? sc.prims[h.prim].material : sc.planes[h.prim - sc.n_prims].material;
-         const rt_material m = sc.materials[mat_id];
-         F3 normal = normal_at(sc, h.prim, ray, h.t);
-         F3 matClr = mk3(m.clr[0], m.clr[1], m.clr[2]);        /* getColor, untextured (kernel.cu:323-326) */
-         F3 eye = normalize3(-ray.d);
-         F3 total = mk3(0.0f, 0.0f, 0.0f);
-         for (int l = 0; l < sc.n_lights; l++) {
-            const rt_dev_light &L = sc.lights[l];
-            F3 lc = mk3(L.clr[0], L.clr[1], L.clr[2]);
-            F3 lightDir = normalize3(mk3(L.pos[0], L.pos[1], L.pos[2]) - P);    /* PointLight.h:14-16 */
-            bool inShadow = flags[(long long)l * n + i] != 0;
-            F3 s = shading == RT_COOK_TORRANCE
-                      ? cook_torrance(matClr, m.amb, m.dif, m.spec, m.rough, eye, lightDir, lc, normal, inShadow)
-                      : phong(matClr, m.amb, m.dif, m.spec, m.rough, eye, lightDir, lc, normal, inShadow);
-            total = total + s;
-         }
-         out.total[0] = total.x; out.total[1] = total.y; out.total[2] = total.z;
+         const rt_material &m = sc.materials[mat_id];
          out.refl = m.refl; out.alpha = m.alpha;
-         if (spawn) {
-            if (m.refl > 0.0f) {
+         if (spawn && (m.refl > 0.0f || m.refr > 0.0f)) {
+            ShadePoint sp = shade_point(sc, queue, i, h);
+            if (sp.m.refl > 0.0f) {
                /* getReflection, kernel.cu:214-216 */
-               reflRay.d = (2.0f * dot3(normal, eye)) * normal - eye;
-               reflRay.o = P + RT_BIG_EPS * reflRay.d;
+               reflRay.d = (2.0f * dot3(sp.normal, sp.eye)) * sp.normal - sp.eye;
+               reflRay.o = sp.P + RT_BIG_EPS * reflRay.d;
                want_refl = true;
             }
-            if (m.refr > 0.0f) {
+            if (sp.m.refr > 0.0f) {
                /* getRefraction, kernel.cu:239-257 */
-               float n1, n2; F3 refrNorm; F3 dd = -eye;
-               if (less_than(dot3(eye, normal), 0.0f)) { n1 = m.ior; n2 = RT_AIR_IOR; refrNorm = -normal; }
-               else { n1 = RT_AIR_IOR; n2 = m.ior; refrNorm = normal; }
+               float n1, n2; F3 refrNorm; F3 dd = -sp.eye;
+               if (less_than(dot3(sp.eye, sp.normal), 0.0f)) { n1 = sp.m.ior; n2 = RT_AIR_IOR; refrNorm = -sp.normal; }
+               else { n1 = RT_AIR_IOR; n2 = sp.m.ior; refrNorm = sp.normal; }
                float dDotN = dot3(dd, refrNorm);
                float nr = n1 / n2;
                float disc = 1.0f - nr * nr * (1.0f - dDotN * dDotN);
                if (disc > 0.0f) {
                   refrRay.d = nr * (dd - refrNorm * dDotN) - refrNorm * sqrtf(disc);
-                  refrRay.o = P + RT_BIG_EPS * refrRay.d;
+                  refrRay.o = sp.P + RT_BIG_EPS * refrRay.d;
                   want_refr = true;
                }
             }
          }
-         shaded = true;
       }
    }
    stat_count(stats, ST_SHADE_NODES, shaded);
@@ -700,44 +705,68 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene sc, const QRay *queue
       unsigned cR = __popcll(mR), cT = __popcll(mT);
       if (cR + cT) {
          unsigned lane = __lane_id();
+         unsigned leader = (unsigned)__ffsll((long long)(mR | mT)) - 1;
          unsigned base = 0;
-         if (lane == (unsigned)__ffsll((long long)(mR | mT)) - 1) base = atomicAdd(next_count, cR + cT);
-         base = __shfl(base, __ffsll((long long)(mR | mT)) - 1);
+         if (lane == leader) base = atomicAdd(next_count, cR + cT);
+         base = __shfl(base, leader);
          unsigned long long below = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
          if (want_refl) {
             unsigned slot = base + __popcll(mR & below);
-            if (slot < next_cap) {
-               store_qray(next_queue, slot, reflRay.o, reflRay.d, -FLT_MAX, 1); out.child_refl = (int)slot;
-            }
+            if (slot < next_cap) { store_qray(next_queue, slot, reflRay.o, reflRay.d, -FLT_MAX, 1); out.child_refl = (int)slot; }
          }
          if (want_refr) {
             unsigned slot = base + cR + __popcll(mT & below);
-            if (slot < next_cap) {
-               store_qray(next_queue, slot, refrRay.o, refrRay.d, -FLT_MAX, 1); out.child_refr = (int)slot;
-            }
+            if (slot < next_cap) { store_qray(next_queue, slot, refrRay.o, refrRay.d, -FLT_MAX, 1); out.child_refr = (int)slot; }
          }
-         if (lane == (unsigned)__ffsll((long long)(mR | mT)) - 1) {
+         if (lane == leader) {
             stat_add(stats, ST_REFLECT, (unsigned long long)cR);
             stat_add(stats, ST_REFRACT, (unsigned long long)cT);
          }
       }
    }
-   if (i < n) nodes[i] = out;
+   if (i < n) *reinterpret_cast<float4 *>(recs + i) = make_float4(out.refl, out.alpha, __int_as_float(out.child_refl), __int_as_float(out.child_refr));
+}
+
+/* light: totalLight of every hit of a level, the loop of kernel.cu:347-358 with the shadow flags of the level */
+__global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue, const Hit *hits, const unsigned char *flags,
+                                                    long long n, int shading, float *totals)
+{
+   long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+   if (i >= n) return;
+   Hit h = hits[i];
+   F3 total = mk3(0.0f, 0.0f, 0.0f);
+   if (h.prim >= 0) {
+      ShadePoint sp = shade_point(sc, queue, i, h);
+      F3 matClr = mk3(sp.m.clr[0], sp.m.clr[1], sp.m.clr[2]);      /* getColor, untextured (kernel.cu:323-326) */
+      for (int l = 0; l < sc.n_lights; l++) {
+         const rt_dev_light &L = sc.lights[l];
+         F3 lc = mk3(L.clr[0], L.clr[1], L.clr[2]);
+         F3 lightDir = normalize3(mk3(L.pos[0], L.pos[1], L.pos[2]) - sp.P);    /* PointLight.h:14-16 */
+         bool inShadow = flags[(long long)l * n + i] != 0;
+         F3 c = shading == RT_COOK_TORRANCE
+                   ? cook_torrance(matClr, sp.m.amb, sp.m.dif, sp.m.spec, sp.m.rough, sp.eye, lightDir, lc, sp.normal, inShadow)
+                   : phong(matClr, sp.m.amb, sp.m.dif, sp.m.spec, sp.m.rough, sp.eye, lightDir, lc, sp.normal, inShadow);
+         total = total + c;
+      }
+   }
+   totals[3 * i] = total.x; totals[3 * i + 1] = total.y; totals[3 * i + 2] = total.z;
 }
 
 /* combine: colour of node i of a level from its own light sum and its children's colours
  * (kernel.cu:375-376).  child colours of a missing ray are the reference's vec3(0). */
-__global__ __launch_bounds__(RT_BLOCK) void k_combine(const ShadeNode *nodes, const float *child_rgb, long long n,
-                                                      float *rgb, int clamp_out)
+__global__ __launch_bounds__(RT_BLOCK) void k_combine(const SpawnRec *recs, const float *totals, const float *child_rgb,
+                                                      long long n, float *rgb, int clamp_out)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
    if (i >= n) return;
-   ShadeNode s = nodes[i];
+   float4 rr = *reinterpret_cast<const float4 *>(recs + i);
+   float w_refl = rr.x, w_alpha = rr.y;
+   int child_refl = __float_as_int(rr.z), child_refr = __float_as_int(rr.w);
    F3 refl = mk3(0.0f, 0.0f, 0.0f), refr = mk3(0.0f, 0.0f, 0.0f);
-   if (s.child_refl >= 0) refl = mk3(child_rgb[3LL * s.child_refl], child_rgb[3LL * s.child_refl + 1], child_rgb[3LL * s.child_refl + 2]);
-   if (s.child_refr >= 0) refr = mk3(child_rgb[3LL * s.child_refr], child_rgb[3LL * s.child_refr + 1], child_rgb[3LL * s.child_refr + 2]);
-   F3 total = mk3(s.total[0], s.total[1], s.total[2]);
-   F3 c = total * (1.0f - s.refl - s.alpha) + s.refl * refl + s.alpha * refr;
+   if (child_refl >= 0) refl = mk3(child_rgb[3LL * child_refl], child_rgb[3LL * child_refl + 1], child_rgb[3LL * child_refl + 2]);
+   if (child_refr >= 0) refr = mk3(child_rgb[3LL * child_refr], child_rgb[3LL * child_refr + 1], child_rgb[3LL * child_refr + 2]);
+   F3 total = mk3(totals[3 * i], totals[3 * i + 1], totals[3 * i + 2]);
+   F3 c = total * (1.0f - w_refl - w_alpha) + w_refl * refl + w_alpha * refr;
    if (clamp_out) {
       /* rayTrace's clamp (kernel.cu:537-539); NaN passes through clamp unchanged (Util.h:28-30) */
       c = mk3(clamp01(c.x), clamp01(c.y), clamp01(c.z));
@@ -849,6 +878,12 @@ struct rt_scene {
    unsigned long long *d_stats;
    unsigned *h_counts;      /* pinned */
    unsigned long long *h_stats;
+   /* Two internal streams: the bounce chain (extend -> spawn -> extend ...) is a sequence of launches each
+    * bounded below by its longest ray, so it runs on `chain` while the shadow rays and
+    * light sums of the levels already extended fill the machine from `side`. */
+   hipStream_t chain, side;
+   hipEvent_t ev_level[RT_MAX_RECURSE], ev_begin, ev_side_done, ev_end;
+   bool streams_ok;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -877,6 +912,11 @@ extern "C" void rt_scene_destroy(rt_scene *s)
    if (s->d_stats) (void)hipFree(s->d_stats);
    if (s->h_counts) (void)hipHostFree(s->h_counts);
    if (s->h_stats) (void)hipHostFree(s->h_stats);
+   if (s->streams_ok) {
+      (void)hipStreamDestroy(s->chain); (void)hipStreamDestroy(s->side);
+      for (int l = 0; l < RT_MAX_RECURSE; l++) (void)hipEventDestroy(s->ev_level[l]);
+      (void)hipEventDestroy(s->ev_begin); (void)hipEventDestroy(s->ev_side_done); (void)hipEventDestroy(s->ev_end);
+   }
    rt_flat_scene_free(&s->host);
    delete s;
 }
@@ -889,7 +929,7 @@ extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
    if (!s) return RT_ERR_BAD_ARGUMENT;
    memset(&s->host, 0, sizeof s->host);
    memset(&s->d, 0, sizeof s->d);
-   s->device = -1; s->flags = 0;
+   s->device = -1; s->flags = 0; s->streams_ok = false;
    s->dev_blob = nullptr; s->dev_bytes = 0; s->d_counts = nullptr; s->d_next = nullptr; s->d_stats = nullptr; s->h_counts = nullptr; s->h_stats = nullptr;
    s->camera = desc->camera; s->has_camera = desc->has_camera; s->ms_upload = 0;
    auto t0 = std::chrono::steady_clock::now();
@@ -912,7 +952,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    rt_scene *s = new (std::nothrow) rt_scene();
    if (!s) return RT_ERR_BAD_ARGUMENT;
    memset(&s->host, 0, sizeof s->host);
-   s->device = device; s->flags = flags;
+   s->device = device; s->flags = flags; s->streams_ok = false;
    s->dev_blob = nullptr; s->d_counts = nullptr; s->d_next = nullptr; s->d_stats = nullptr; s->h_counts = nullptr; s->h_stats = nullptr;
    s->camera = desc->camera; s->has_camera = desc->has_camera;
 
@@ -953,6 +993,16 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
        hipHostMalloc((void **)&s->h_counts, 64 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
        hipHostMalloc((void **)&s->h_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
       rt_set_error("allocation of queue counters failed"); rt_scene_destroy(s); return RT_ERR_HIP;
+   }
+   {
+      bool ok = hipStreamCreateWithFlags(&s->chain, hipStreamNonBlocking) == hipSuccess;
+      ok = ok && hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) == hipSuccess;
+      for (int l = 0; l < RT_MAX_RECURSE && ok; l++) ok = hipEventCreateWithFlags(&s->ev_level[l], hipEventDisableTiming) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&s->ev_begin, hipEventDisableTiming) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&s->ev_side_done, hipEventDisableTiming) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&s->ev_end, hipEventDisableTiming) == hipSuccess;
+      if (!ok) { rt_set_error("stream / event creation failed"); rt_scene_destroy(s); return RT_ERR_HIP; }
+      s->streams_ok = true;
    }
    e = hipDeviceSynchronize();
    if (e != hipSuccess) { rt_set_error("scene upload failed: %s", hipGetErrorString(e)); rt_scene_destroy(s); return RT_ERR_HIP; }
@@ -1028,7 +1078,8 @@ struct LevelBufs {
    long long n = 0;
    size_t queue = 0;      /* QRay[n], level >= 1 */
    size_t hits = 0;       /* Hit[n] */
-   size_t nodes = 0;      /* ShadeNode[n] */
+   size_t recs = 0;       /* SpawnRec[n] */
+   size_t totals = 0;     /* float[3n]: light sums */
    size_t rgb = 0;        /* float[3n] */
    size_t slow = 0;       /* unsigned[n]: rays set aside for the literal-arithmetic kernel */
    bool has_queue = false;
@@ -1175,9 +1226,14 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    size_t lds_bytes = 0;
    { int rc = trace_lds_bytes(s, &lds_bytes); if (rc != RT_OK) return rc; }
 
-   HIP_TRY(hipMemsetAsync(s->d_stats, 0, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), stream));
+   /* the caller's stream brackets the frame; the work itself runs on the two internal streams */
+   hipStream_t M = s->chain, H = s->side;
+   { const char *e = getenv("RT_SINGLE_STREAM"); if (e && atoi(e)) H = M; }
    EventPool ev;
    Timer &t_total = ev.begin(stream, &st.ms_total);
+   HIP_TRY(hipEventRecord(s->ev_begin, stream));
+   HIP_TRY(hipStreamWaitEvent(M, s->ev_begin, 0));
+   HIP_TRY(hipMemsetAsync(s->d_stats, 0, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), M));
 
    for (long long k0 = 0; k0 < n_sel; k0 += tiles_per_batch) {
       long long nb = n_sel - k0 < tiles_per_batch ? n_sel - k0 : tiles_per_batch;
@@ -1186,12 +1242,13 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       lv[0].n = nb * per_tile;
 
       /* Arena: a bump allocator re-used by every frame.  Level l+1's queue is carved for the worst case
-       * (two rays per node of level l) and trimmed to the real count once that is known. */
+       * (two rays per node of level l) and trimmed to the real count once that is known; everything else
+       * of a batch stays allocated until the batch is done, because the side stream works behind the chain. */
       size_t used = 0;
       auto carve = [&](size_t bytes) { size_t o = used; used += align_up(bytes ? bytes : 1, 256); return o; };
       auto grow = [&](size_t keep) -> int {
          if (used <= s->arena.cap) return RT_OK;
-         HIP_TRY(hipStreamSynchronize(stream));
+         HIP_TRY(hipDeviceSynchronize());
          Arena bigger;
          int rc = arena_reserve(bigger, used * 2);
          if (rc != RT_OK) return rc;
@@ -1200,27 +1257,33 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          s->arena = bigger;
          return RT_OK;
       };
+      auto carve_level = [&](LevelBufs &b) {
+         b.hits = carve(sizeof(Hit) * (size_t)b.n);
+         b.recs = carve(sizeof(SpawnRec) * (size_t)b.n);
+         b.totals = carve(sizeof(float) * 3 * (size_t)b.n);
+         b.rgb = carve(sizeof(float) * 3 * (size_t)b.n);
+         b.slow = carve(sizeof(unsigned) * (size_t)b.n);
+      };
+      if (k0 > 0) HIP_TRY(hipDeviceSynchronize());   /* the previous batch still owns the arena */
       lv[0].queue = carve(sizeof(QRay) * (size_t)lv[0].n); lv[0].has_queue = true;
-      lv[0].hits = carve(sizeof(Hit) * (size_t)lv[0].n);
-      lv[0].nodes = carve(sizeof(ShadeNode) * (size_t)lv[0].n);
-      lv[0].rgb = carve(sizeof(float) * 3 * (size_t)lv[0].n);
-      lv[0].slow = carve(sizeof(unsigned) * (size_t)lv[0].n);
+      carve_level(lv[0]);
       { int rc = grow(0); if (rc != RT_OK) return rc; }
 #define AT(T, off) ((T *)(s->arena.base + (off)))
 
-      HIP_TRY(hipMemsetAsync(s->d_counts, 0, 64 * sizeof(unsigned), stream));
-      HIP_TRY(hipMemsetAsync(s->d_next, 0, 64 * sizeof(unsigned long long), stream));
+      HIP_TRY(hipMemsetAsync(s->d_counts, 0, 64 * sizeof(unsigned), M));
+      HIP_TRY(hipMemsetAsync(s->d_next, 0, 64 * sizeof(unsigned long long), M));
       int n_trace = 0;   /* index of the next unused work counter */
 
       {  /* level 0: generate the primary rays, then their closest hits */
-         Timer &tg = ev.begin(stream, &st.ms_generate);
-         hipLaunchKernelGGL(k_generate, dim3(grid_for(lv[0].n)), dim3(RT_BLOCK), 0, stream, cam, g, lv[0].n, AT(QRay, lv[0].queue),
+         Timer &tg = ev.begin(M, &st.ms_generate);
+         hipLaunchKernelGGL(k_generate, dim3(grid_for(lv[0].n)), dim3(RT_BLOCK), 0, M, cam, g, lv[0].n, AT(QRay, lv[0].queue),
                             AT(Hit, lv[0].hits), s->d_stats);
-         ev.end(tg, stream);
-         Timer &tm = ev.begin(stream, &st.ms_extend);
+         ev.end(tg, M);
+         Timer &tm = ev.begin(M, &st.ms_extend);
          launch_trace(s, false, count, AT(QRay, lv[0].queue), (unsigned long long)lv[0].n, AT(Hit, lv[0].hits), nullptr,
-                      s->d_next + 2 * n_trace++, AT(unsigned, lv[0].slow), lds_bytes, stream);
-         ev.end(tm, stream); st.launches_extend++;
+                      s->d_next + 2 * n_trace++, AT(unsigned, lv[0].slow), lds_bytes, M);
+         ev.end(tm, M); st.launches_extend++;
+         HIP_TRY(hipEventRecord(s->ev_level[0], M));
       }
 
       int last = 0;
@@ -1238,88 +1301,103 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
                next_cap = (unsigned)cap;
                nextq_off = carve(sizeof(QRay) * (size_t)next_cap);
             }
-            /* shadow flags and the shadow-ray queue of this level live past the next queue: dropped as soon as
-             * the level is shaded */
+            { int rc = grow(live); if (rc != RT_OK) return rc; }
+            const QRay *queue = AT(QRay, lv[l].queue);
+            {  /* chain: the next level's rays */
+               Timer &tm = ev.begin(M, &st.ms_shade);
+               hipLaunchKernelGGL(k_spawn, dim3(grid_for(n)), dim3(RT_BLOCK), 0, M, sc, queue, (const Hit *)AT(Hit, lv[l].hits), n,
+                                  spawn, AT(SpawnRec, lv[l].recs), spawn ? AT(QRay, nextq_off) : (QRay *)nullptr,
+                                  s->d_counts + (l + 1), next_cap, s->d_stats);
+               ev.end(tm, M);
+            }
+            long long n_next = 0;
+            if (spawn) {
+               HIP_TRY(hipMemcpyAsync(s->h_counts, s->d_counts + (l + 1), sizeof(unsigned), hipMemcpyDeviceToHost, M));
+               HIP_TRY(hipStreamSynchronize(M));
+               n_next = s->h_counts[0];
+               if (n_next > next_cap) n_next = next_cap;
+               /* keep the spawned rays, release the unused queue tail */
+               used = nextq_off + align_up(sizeof(QRay) * (size_t)(n_next ? n_next : 1), 256);
+            }
+            live = used;
+            /* side: shadow rays and light sums of this level, behind its extend */
             unsigned long long n_shadow = (unsigned long long)(L > 0 ? L : 0) * (unsigned long long)n;
             size_t flags_off = carve((size_t)(n_shadow ? n_shadow : 1));
             size_t shq_off = carve(sizeof(QRay) * (size_t)(n_shadow ? n_shadow : 1));
             size_t shslow_off = carve(sizeof(unsigned) * (size_t)(n_shadow ? n_shadow : 1));
-            { int rc = grow(live); if (rc != RT_OK) return rc; }
-            const QRay *queue = AT(QRay, lv[l].queue);
-
-            if (L > 0 && n > 0) {
-               Timer &ts = ev.begin(stream, &st.ms_shadow_setup);
-               dim3 grid(grid_for(n), (unsigned)L);
-               hipLaunchKernelGGL(k_shadow_setup, grid, dim3(RT_BLOCK), 0, stream, sc, queue, (const Hit *)AT(Hit, lv[l].hits), n,
-                                  AT(QRay, shq_off), AT(unsigned char, flags_off), s->d_stats);
-               ev.end(ts, stream);
-               Timer &tm = ev.begin(stream, &st.ms_shadow);
-               launch_trace(s, true, count, AT(QRay, shq_off), n_shadow, nullptr, AT(unsigned char, flags_off),
-                            s->d_next + 2 * n_trace++, AT(unsigned, shslow_off), lds_bytes, stream);
-               ev.end(tm, stream); st.launches_shadow++;
+            if (n_next > 0) {
+               lv[l + 1].n = n_next;
+               lv[l + 1].queue = nextq_off; lv[l + 1].has_queue = true;
+               carve_level(lv[l + 1]);
             }
-            {
-               Timer &tm = ev.begin(stream, &st.ms_shade);
-               hipLaunchKernelGGL(k_shade, dim3(grid_for(n)), dim3(RT_BLOCK), 0, stream, sc,
-                                  queue, (const Hit *)AT(Hit, lv[l].hits), (const unsigned char *)AT(unsigned char, flags_off), n,
-                                  p->shading, spawn, AT(ShadeNode, lv[l].nodes), spawn ? AT(QRay, nextq_off) : (QRay *)nullptr,
-                                  s->d_counts + (l + 1), next_cap, s->d_stats);
-               ev.end(tm, stream);
-            }
-            if (!spawn) break;
-            HIP_TRY(hipMemcpyAsync(s->h_counts, s->d_counts + (l + 1), sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-            long long n_next = s->h_counts[0];
-            if (n_next > next_cap) n_next = next_cap;
-            if (n_next == 0) break;
-            /* keep the spawned rays; the flags and the unused queue tail are released */
-            used = nextq_off + align_up(sizeof(QRay) * (size_t)n_next, 256);
-            live = used;
-            lv[l + 1].n = n_next;
-            lv[l + 1].queue = nextq_off; lv[l + 1].has_queue = true;
-            lv[l + 1].hits = carve(sizeof(Hit) * (size_t)n_next);
-            lv[l + 1].nodes = carve(sizeof(ShadeNode) * (size_t)n_next);
-            lv[l + 1].rgb = carve(sizeof(float) * 3 * (size_t)n_next);
-            lv[l + 1].slow = carve(sizeof(unsigned) * (size_t)n_next);
             { int rc = grow(live); if (rc != RT_OK) return rc; }
-            {
-               Timer &tm = ev.begin(stream, &st.ms_extend);
+            queue = AT(QRay, lv[l].queue);
+            if (n_next > 0) {
+               /* chain first: the next extend is on the critical path */
+               Timer &tm = ev.begin(M, &st.ms_extend);
                launch_trace(s, false, count, AT(QRay, lv[l + 1].queue), (unsigned long long)n_next, AT(Hit, lv[l + 1].hits), nullptr,
-                            s->d_next + 2 * n_trace++, AT(unsigned, lv[l + 1].slow), lds_bytes, stream);
-               ev.end(tm, stream); st.launches_extend++;
+                            s->d_next + 2 * n_trace++, AT(unsigned, lv[l + 1].slow), lds_bytes, M);
+               ev.end(tm, M); st.launches_extend++;
+               HIP_TRY(hipEventRecord(s->ev_level[l + 1], M));
             }
+            HIP_TRY(hipStreamWaitEvent(H, s->ev_level[l], 0));
+            if (L > 0 && n > 0) {
+               Timer &ts = ev.begin(H, &st.ms_shadow_setup);
+               dim3 grid(grid_for(n), (unsigned)L);
+               hipLaunchKernelGGL(k_shadow_setup, grid, dim3(RT_BLOCK), 0, H, sc, queue, (const Hit *)AT(Hit, lv[l].hits), n,
+                                  AT(QRay, shq_off), AT(unsigned char, flags_off), s->d_stats);
+               ev.end(ts, H);
+               Timer &tm = ev.begin(H, &st.ms_shadow);
+               launch_trace(s, true, count, AT(QRay, shq_off), n_shadow, nullptr, AT(unsigned char, flags_off),
+                            s->d_next + 2 * n_trace++, AT(unsigned, shslow_off), lds_bytes, H);
+               ev.end(tm, H); st.launches_shadow++;
+            }
+            {
+               Timer &tm = ev.begin(H, &st.ms_light);
+               hipLaunchKernelGGL(k_light, dim3(grid_for(n)), dim3(RT_BLOCK), 0, H, sc, queue, (const Hit *)AT(Hit, lv[l].hits),
+                                  (const unsigned char *)AT(unsigned char, flags_off), n, p->shading, AT(float, lv[l].totals));
+               ev.end(tm, H);
+            }
+            if (n_next == 0) break;
          }
-         /* bottom-up combine */
-         Timer &tc = ev.begin(stream, &st.ms_combine);
+         /* bottom-up combine once both streams are through */
+         HIP_TRY(hipEventRecord(s->ev_side_done, H));
+         HIP_TRY(hipStreamWaitEvent(M, s->ev_side_done, 0));
+         Timer &tc = ev.begin(M, &st.ms_combine);
          for (int l = last; l >= 0; l--) {
             const float *child = (l < last) ? AT(float, lv[l + 1].rgb) : nullptr;
             /* the deepest level has no children: every child index is -1 there */
-            hipLaunchKernelGGL(k_combine, dim3(grid_for(lv[l].n)), dim3(RT_BLOCK), 0, stream, (const ShadeNode *)AT(ShadeNode, lv[l].nodes),
-                               child, lv[l].n, AT(float, lv[l].rgb), l == 0 ? 1 : 0);
+            hipLaunchKernelGGL(k_combine, dim3(grid_for(lv[l].n)), dim3(RT_BLOCK), 0, M, (const SpawnRec *)AT(SpawnRec, lv[l].recs),
+                               (const float *)AT(float, lv[l].totals), child, lv[l].n, AT(float, lv[l].rgb), l == 0 ? 1 : 0);
          }
-         ev.end(tc, stream);
+         ev.end(tc, M);
       }
 
       if (view == VIEW_FRAME) {
-         Timer &tr = ev.begin(stream, &st.ms_resolve);
+         Timer &tr = ev.begin(M, &st.ms_resolve);
          long long npx = nb * RT_TILE * RT_TILE;
-         hipLaunchKernelGGL(k_resolve, dim3(grid_for(npx)), dim3(RT_BLOCK), 0, stream, g, (const float *)AT(float, lv[0].rgb), (int)nb,
+         hipLaunchKernelGGL(k_resolve, dim3(grid_for(npx)), dim3(RT_BLOCK), 0, M, g, (const float *)AT(float, lv[0].rgb), (int)nb,
                             p->out_layout, (uchar4 *)out_dev);
-         ev.end(tr, stream);
+         ev.end(tr, M);
       } else if (view == VIEW_PRIMARY) {
-         hipLaunchKernelGGL(k_unslot_hits, dim3(grid_for(lv[0].n)), dim3(RT_BLOCK), 0, stream, g, (const Hit *)AT(Hit, lv[0].hits), lv[0].n,
+         hipLaunchKernelGGL(k_unslot_hits, dim3(grid_for(lv[0].n)), dim3(RT_BLOCK), 0, M, g, (const Hit *)AT(Hit, lv[0].hits), lv[0].n,
                             prim_dev, t_dev);
       } else {
-         hipLaunchKernelGGL(k_unslot_rgb, dim3(grid_for(lv[0].n)), dim3(RT_BLOCK), 0, stream, g, (const float *)AT(float, lv[0].rgb), lv[0].n,
+         hipLaunchKernelGGL(k_unslot_rgb, dim3(grid_for(lv[0].n)), dim3(RT_BLOCK), 0, M, g, (const float *)AT(float, lv[0].rgb), lv[0].n,
                             rgb_dev);
       }
       HIP_TRY(hipGetLastError());
    }
+   HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipMemcpyDeviceToHost, M));
+   HIP_TRY(hipEventRecord(s->ev_end, M));
+   HIP_TRY(hipStreamWaitEvent(stream, s->ev_end, 0));
    ev.end(t_total, stream);
-   HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
    HIP_TRY(hipStreamSynchronize(stream));
+   HIP_TRY(hipStreamSynchronize(M));
+   HIP_TRY(hipStreamSynchronize(H));
    HIP_TRY(hipGetLastError());
    ev.collect();
+   if (sum_stat(s->h_stats, ST_ABORTED) != 0) { rt_set_error("traversal aborted: step cap reached (corrupt scene?)"); return RT_ERR_HIP; }
    st.rays_primary = sum_stat(s->h_stats, ST_PRIMARY);
    st.rays_shadow = sum_stat(s->h_stats, ST_SHADOW_TRACED);
    st.shadow_skipped = sum_stat(s->h_stats, ST_SHADOW_SKIPPED);
