@@ -143,6 +143,8 @@ typedef struct rt_stats {
    /* wave-level step counts (one per wave per executed node step / leaf step): lane utilisation of
     * the traversal loop = node_visits / (64 * wave_node_steps) */
    uint64_t wave_node_steps, wave_leaf_steps, wave_node_steps_shadow, wave_leaf_steps_shadow;
+   /* the longest single ray, in wave steps it was in flight: the serial floor of a traversal launch */
+   uint64_t max_ray_steps, max_ray_steps_shadow;
 } rt_stats;
 
 typedef struct rt_scene_info {

@@ -45,7 +45,9 @@ __device__ __forceinline__ F3 normalize3(F3 v)
 /* Util.h:8-42 */
 __device__ __forceinline__ bool is_zero(float n) { return n < RT_EPS && n > -RT_EPS; }
 __device__ __forceinline__ bool is_equal(float a, float b) { return a + RT_EQ_EPS > b && b + RT_EQ_EPS > a; }
-__device__ __forceinline__ bool above_zero(float n) { return n + RT_EPS > 0.0f; }
+/* n + EPSILON > 0 (Util.h:16-18).  The sum of two floats keeps the sign of the exact sum and is zero only
+ * when that is zero, so this is the same predicate as n > -EPSILON, one instruction shorter. */
+__device__ __forceinline__ bool above_zero(float n) { return n > -RT_EPS; }
 __device__ __forceinline__ bool less_than(float l, float r) { return l + RT_EPS < r; }
 __device__ __forceinline__ float clamp01(float x) { return x > 1.0f ? 1.0f : x < 0.0f ? 0.0f : x; }
 __device__ __forceinline__ float my_min(float x, float y) { return x < y ? x : y; }
@@ -73,18 +75,21 @@ __device__ __forceinline__ Ray ray_transform(const Ray &r, const rt_dev_xform &m
  * box (GeometryUtil.h:17-32) and the quotients are compared with each other
  * and with t, so they must be the correctly rounded a/d.  hipcc's own a/d is
  * ~10 instructions; with y = RN(1/d) computed once per ray (a true division)
- * two residual corrections give RN(a/d) in 5 (Markstein: q' = q + (a - d*q)*y
- * is correctly rounded once q is within an ulp and y = RN(1/d)).
- * Valid while a, d, the quotient and the residuals stay normal; a wave with a
- * ray whose origin or direction is outside [2^-40, 2^40] (zero allowed for the
- * origin) takes the literal path below instead. */
+ * one residual correction gives RN(a/d) in 3:
+ *      q0 = RN(a*y);  r = a - d*q0 (one fma);  q = RN(q0 + r*y) (one fma).
+ * q0 is within 1.5 ulp of a/d, so q0 + r*y differs from a/d by less than
+ * 2^-22 ulp and the last rounding can only go wrong when a/d lies that close
+ * to the midpoint of two floats.  Those operand pairs are few enough to list
+ * (about 5e7 significand pairs) and every one of them is checked against a
+ * true division by tests/native/exact_div_hard_cases.c.
+ * Valid while a, d, the quotient and the residual stay normal; a ray whose
+ * origin or direction is outside [2^-40, 2^40] (zero allowed for the origin)
+ * takes the literal path below instead. */
 __device__ __forceinline__ float rt_div(float a, float d, float y)
 {
    float q0 = a * y;
    float r0 = __builtin_fmaf(-d, q0, a);
-   float q1 = __builtin_fmaf(r0, y, q0);
-   float r1 = __builtin_fmaf(-d, q1, a);
-   return __builtin_fmaf(r1, y, q1);
+   return __builtin_fmaf(r0, y, q0);
 }
 
 __device__ __forceinline__ bool in_div_range(float v)

@@ -91,7 +91,7 @@ struct SpawnRec {
 enum { ST_SHADOW_TRACED = 0, ST_SHADOW_SKIPPED, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES, ST_PRIMARY,
        ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
        ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_WAVE_NODE_STEPS_SHADOW, ST_WAVE_LEAF_STEPS_SHADOW,
-       ST_ABORTED, ST_COUNT };
+       ST_ABORTED, ST_MAX_RAY_STEPS, ST_MAX_RAY_STEPS_SHADOW, ST_COUNT };
 
 /* Statistics counters are replicated RT_STAT_REPL times (blocks spread over the replicas, the host
  * sums them) and bumped once per wave, so that counting does not serialise the kernels on one word. */
@@ -332,9 +332,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
    int closest = -1, cur = 0, sp = 0;
    unsigned idx = 0;
    unsigned nv = 0, np = 0, nt = 0, wn = 0, wl = 0;
+   unsigned ray_steps = 0, max_ray_steps = 0;   /* COUNT only: wave steps this ray has been in flight */
 
    /* a ray is finished: scan the planes unless it left early, write its result */
    auto finish = [&](bool early) {
+      if (COUNT) { max_ray_steps = ray_steps > max_ray_steps ? ray_steps : max_ray_steps; }
       if (!early) plane_scan(sc, c.r, t, closest);
       if (OUT == OUT_HIT) { Hit h; h.prim = closest; h.t = t; hits[idx] = h; }
       else flags[idx] = less_than(t, toBeat) ? 1 : 0;            /* kernel.cu:206 */
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
                   if (c.fast && sc.fast_ok) {
                      toBeat = q.to_beat; idx = (unsigned)my;
                      t = FLT_MAX; closest = -1; sp = 0; cur = sc.root;
-                     active = true;
+                     active = true; ray_steps = 0;
                      if (cur == RT_ROOT_EMPTY) finish(false);
                   } else {
                      slow_list[atomicAdd(slow_count, 1u)] = (unsigned)my;
@@ -395,30 +397,33 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
       for (int burst = 0; burst < RT_NODE_BURST; burst++) {
          bool in_node = active && cur >= 0;
          if (__ballot(in_node) == 0) break;
-         if (COUNT) wn++;
+         if (COUNT) { wn++; if (active) ray_steps++; }
          if (in_node) {
-            float4 a, b, cc, d;
-            load_node(sc.nodes, cur, a, b, cc, d);
+            /* 56 of the record's 64 bytes: two boxes and the two child references */
+            const char *rec = reinterpret_cast<const char *>(sc.nodes) + ((unsigned)cur << 6);
+            float4 a = *reinterpret_cast<const float4 *>(rec);
+            float4 b = *reinterpret_cast<const float4 *>(rec + 16);
+            float4 cc = *reinterpret_cast<const float4 *>(rec + 32);
+            int2 ch = *reinterpret_cast<const int2 *>(rec + 48);
             if (COUNT) nv++;
             float left = slab_fast(c, a.x, a.y, a.z, a.w, b.x, b.y);
             float right = slab_fast(c, b.z, b.w, cc.x, cc.y, cc.z, cc.w);
-            int li = __float_as_int(d.x), ri = __float_as_int(d.y);
+            /* kernel.cu:148-158 as predicates: right first on `<=`, the other child deferred if it is ahead too */
             bool aL = above_zero(left), aR = above_zero(right);
-            if (aR && (right <= left || !aL) && right < t) {
-               if (aL) { StackEntry e; e.child = li; e.dist = left; stack[sp * stride] = e; sp++; }
-               cur = ri;
-            } else if (aL && (left <= right || !aR) && left < t) {
-               if (aR) { StackEntry e; e.child = ri; e.dist = right; stack[sp * stride] = e; sp++; }
-               cur = li;
-            } else {
-               pop();
+            bool goR = aR && (right <= left || !aL) && right < t;
+            bool goL = !goR && aL && (left <= right || !aR) && left < t;
+            if ((goR && aL) || (goL && aR)) {
+               StackEntry e; e.child = goR ? ch.x : ch.y; e.dist = goR ? left : right;
+               stack[sp * stride] = e; sp++;
             }
+            if (goR || goL) cur = goR ? ch.y : ch.x;
+            else pop();
          }
       }
       /* ---- leaf step ---- */
       bool at_leaf = active && cur < 0;
       if (__ballot(at_leaf) != 0) {
-         if (COUNT) wl++;
+         if (COUNT) { wl++; if (active) ray_steps++; }
          if (at_leaf) {
             if (COUNT) np++;
             if (leaf_test(sc, c.r, ~cur, toBeat, t, closest, nt)) finish(true);
@@ -434,6 +439,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
          stat_add(stats, stat_base + 3, (unsigned long long)wn);
          stat_add(stats, stat_base + 4, (unsigned long long)wl);
       }
+      atomicMax(&stats[(stat_base == ST_NODE_VISITS ? ST_MAX_RAY_STEPS : ST_MAX_RAY_STEPS_SHADOW) * RT_STAT_REPL],
+                (unsigned long long)max_ray_steps);
    }
 }
 
@@ -1410,6 +1417,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    st.node_visits_shadow = sum_stat(s->h_stats, ST_NODE_VISITS_SHADOW); st.prim_tests_shadow = sum_stat(s->h_stats, ST_PRIM_TESTS_SHADOW);
    st.tie_events_shadow = sum_stat(s->h_stats, ST_TIES_SHADOW);
    st.wave_node_steps = sum_stat(s->h_stats, ST_WAVE_NODE_STEPS); st.wave_leaf_steps = sum_stat(s->h_stats, ST_WAVE_LEAF_STEPS);
+   st.max_ray_steps = s->h_stats[ST_MAX_RAY_STEPS * RT_STAT_REPL]; st.max_ray_steps_shadow = s->h_stats[ST_MAX_RAY_STEPS_SHADOW * RT_STAT_REPL];
    st.wave_node_steps_shadow = sum_stat(s->h_stats, ST_WAVE_NODE_STEPS_SHADOW); st.wave_leaf_steps_shadow = sum_stat(s->h_stats, ST_WAVE_LEAF_STEPS_SHADOW);
    if (stats_out) *stats_out = st;
    return RT_OK;

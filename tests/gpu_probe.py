@@ -17,5 +17,5 @@ with ra.Scene(sd) as sc:
 with ra.Scene(sd, counters=True) as sc:
     frame, st = sc.render(w, h, samples, shading, abi.RT_JITTER_HASH)
     n_ext = st['rays_primary'] + st['rays_reflect'] + st['rays_refract']
-    print(f"  extend: visits/ray {st['node_visits']/max(1,n_ext):.1f} prim/ray {st['prim_tests']/max(1,n_ext):.2f} lane-util node {st['node_visits']/max(1,64*st['wave_node_steps']):.3f} leaf {st['prim_tests']/max(1,64*st['wave_leaf_steps']):.3f} ties {st['tie_events']}")
-    print(f"  shadow: visits/ray {st['node_visits_shadow']/max(1,st['rays_shadow']):.1f} prim/ray {st['prim_tests_shadow']/max(1,st['rays_shadow']):.2f} lane-util node {st['node_visits_shadow']/max(1,64*st['wave_node_steps_shadow']):.3f} leaf {st['prim_tests_shadow']/max(1,64*st['wave_leaf_steps_shadow']):.3f}")
+    print(f"  extend: visits/ray {st['node_visits']/max(1,n_ext):.1f} prim/ray {st['prim_tests']/max(1,n_ext):.2f} lane-util node {st['node_visits']/max(1,64*st['wave_node_steps']):.3f} leaf {st['prim_tests']/max(1,64*st['wave_leaf_steps']):.3f} ties {st['tie_events']} max-ray-steps {st['max_ray_steps']} wave-steps {st['wave_node_steps']+st['wave_leaf_steps']}")
+    print(f"  shadow: visits/ray {st['node_visits_shadow']/max(1,st['rays_shadow']):.1f} prim/ray {st['prim_tests_shadow']/max(1,st['rays_shadow']):.2f} lane-util node {st['node_visits_shadow']/max(1,64*st['wave_node_steps_shadow']):.3f} leaf {st['prim_tests_shadow']/max(1,64*st['wave_leaf_steps_shadow']):.3f} max-ray-steps {st['max_ray_steps_shadow']} wave-steps {st['wave_node_steps_shadow']+st['wave_leaf_steps_shadow']}")
