@@ -1434,6 +1434,7 @@ extern "C" int rt_render(const rt_scene *scene, const rt_render_params *params, 
 {
    if (!scene || !params || !out_host) { rt_set_error("rt_render: null argument"); return RT_ERR_BAD_ARGUMENT; }
    if (params->width <= 0 || params->height <= 0) { rt_set_error("rt_render: non-positive size"); return RT_ERR_BAD_ARGUMENT; }
+   if (scene->device < 0) { rt_set_error("scene was created without a device"); return RT_ERR_NO_DEVICE; }
    HIP_TRY(hipSetDevice(scene->device));
    rt_render_params p = *params;
    p.out_layout = RT_OUT_FRAME;
@@ -1466,6 +1467,7 @@ extern "C" int rt_trace_primary(const rt_scene *scene, const rt_render_params *p
    if (!scene || !params || !prim_host || !t_host) { rt_set_error("rt_trace_primary: null argument"); return RT_ERR_BAD_ARGUMENT; }
    int sroot = isqrt_trunc(params->sample_count);
    if (sroot <= 0 || sroot * sroot != params->sample_count) { rt_set_error("Invalid sample count: %d", params->sample_count); return RT_ERR_BAD_SAMPLE_COUNT; }
+   if (scene->device < 0) { rt_set_error("scene was created without a device"); return RT_ERR_NO_DEVICE; }
    HIP_TRY(hipSetDevice(scene->device));
    size_t n = (size_t)params->width * sroot * (size_t)params->height * sroot;
    int *d_prim = nullptr; float *d_t = nullptr;
@@ -1487,6 +1489,7 @@ extern "C" int rt_render_samples(const rt_scene *scene, const rt_render_params *
    if (!scene || !params || !rgb_host) { rt_set_error("rt_render_samples: null argument"); return RT_ERR_BAD_ARGUMENT; }
    int sroot = isqrt_trunc(params->sample_count);
    if (sroot <= 0 || sroot * sroot != params->sample_count) { rt_set_error("Invalid sample count: %d", params->sample_count); return RT_ERR_BAD_SAMPLE_COUNT; }
+   if (scene->device < 0) { rt_set_error("scene was created without a device"); return RT_ERR_NO_DEVICE; }
    HIP_TRY(hipSetDevice(scene->device));
    size_t n = (size_t)params->width * sroot * (size_t)params->height * sroot;
    float *d_rgb = nullptr;

@@ -4,8 +4,9 @@
  * The reference converts each uchar4 channel k to a double k/255.0, stores it
  * in an Image whose running maximum starts at 1.0, and WriteTga() then emits
  * (unsigned char)((value / max) * 255) (raytrace.cpp:44-55, Image.cpp:10-14,
- * 77-101, 189-205).  max can never exceed 1.0 for byte input, and the double
- * round trip (k/255.0)*255 truncates to k-1 for some k; both are kept.
+ * 77-101, 189-205).  max can never exceed 1.0 for byte input; the double round
+ * trip (k/255.0)*255 is evaluated as the reference evaluates it (it happens
+ * to give back k for all 256 values).
  * Header: 18 bytes, type 2, 24 bits, origin bottom-left; pixels BGR, rows
  * bottom to top -- the frame's row 0 is already the bottom row.
  */

@@ -1,0 +1,105 @@
+"""The bench workload at its full size (balls2, 1920x1080): oracle parity plus size-independent properties.
+
+  * oracle parity of the whole frame (primary ids + hit distances bit for bit, pixels within 1/255)
+  * the frame is a pure function of (scene, params): two renders are the same bytes
+  * tile-partition invariance: N parts rendered separately (what N ranks do) un-tile to the same bytes
+  * the ray bookkeeping adds up, and the counted run sees the same rays as the uncounted one
+"""
+import os
+
+import numpy as np
+import pytest
+
+import orclib
+import raytracer_amd as ra
+from raytracer_amd import abi, tiles
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+W, H = 1920, 1080
+
+
+@pytest.fixture(scope="module")
+def balls2():
+    return ra.SceneData.load(os.path.join(GOLDEN, "scenes", "balls2.npz"))
+
+
+@pytest.fixture(scope="module")
+def full(balls2):
+    with ra.Scene(balls2) as sc:
+        frame, st = sc.render(W, H, 1, abi.RT_PHONG, abi.RT_JITTER_HASH)
+        prim, t = sc.trace_primary(W, H, 1, abi.RT_JITTER_HASH)
+    return frame, st, prim, t
+
+
+def test_full_frame_against_oracle(balls2, full):
+    frame, st, prim, t = full
+    osc = orclib.OracleScene(balls2)
+    ref = osc.render(W, H, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, want_samples=False)
+    osc.close()
+    assert np.array_equal(prim, ref["prim"])
+    assert np.array_equal(t.view(np.uint32), ref["t"].view(np.uint32))
+    c = ref["counters"]
+    assert (st["rays_primary"], st["rays_reflect"], st["rays_refract"]) == (c["rays_primary"], c["rays_reflect"], c["rays_refract"])
+    assert st["rays_shadow"] + st["shadow_skipped"] == c["rays_shadow"]
+    diff = np.abs(frame[:, :, :3].astype(int) - ref["rgba"][:, :, :3].astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.999, f"{(diff > 1).sum()} pixels off by more than 1"
+
+
+def test_same_bytes_twice(balls2, full):
+    with ra.Scene(balls2) as sc:
+        a, st_a = sc.render(W, H, 1, abi.RT_PHONG, abi.RT_JITTER_HASH)
+        b, st_b = sc.render(W, H, 1, abi.RT_PHONG, abi.RT_JITTER_HASH)
+    assert a.tobytes() == b.tobytes() == full[0].tobytes()
+    assert st_a["rays_total"] == st_b["rays_total"] == full[1]["rays_total"]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_tile_partition_invariance(balls2, full, world):
+    import torch
+    lib = abi.load_library()
+    stride = tiles.part_bytes(W, H, world)
+    parts = torch.zeros(world * stride, dtype=torch.uint8, device="cuda")
+    frame = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    rays = 0
+    with ra.Scene(balls2) as sc:
+        for r in range(world):
+            p = ra.make_params(W, H, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, 0, 0, r, world, abi.RT_OUT_TILES)
+            st = sc.render_device(p, parts.data_ptr() + r * stride, stream)
+            assert st["samples"] <= ra.tile_count(W, H, r, world) * 32 * 32
+            rays += st["rays_total"]
+    assert lib.rt_untile_device(parts.data_ptr(), stride, world, W, H, frame.data_ptr(), stream) == 0
+    torch.cuda.synchronize()
+    got = frame.cpu().numpy().reshape(H, W, 4)
+    assert got.tobytes() == full[0].tobytes()
+    assert rays == full[1]["rays_total"]
+    assert tiles.untile_host(parts.cpu().numpy(), stride, world, W, H).tobytes() == full[0].tobytes()
+
+
+def test_ray_bookkeeping_and_counters(balls2, full):
+    _, st, _, _ = full
+    assert st["rays_primary"] == W * H == st["samples"]
+    assert st["rays_total"] == st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"] + st["rays_refract"]
+    assert st["shade_nodes"] <= st["rays_primary"] + st["rays_reflect"] + st["rays_refract"]
+    assert st["rays_shadow"] + st["shadow_skipped"] == st["shade_nodes"] * len(balls2.lights)
+    with ra.Scene(balls2, counters=True) as sc:
+        frame, cst = sc.render(W, H, 1, abi.RT_PHONG, abi.RT_JITTER_HASH)
+    assert frame.tobytes() == full[0].tobytes()
+    for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "shade_nodes"):
+        assert cst[k] == st[k]
+    assert cst["node_visits"] > cst["rays_primary"] and cst["prim_tests"] > 0 and cst["node_visits_shadow"] > 0
+
+
+def test_antialiased_vga_frame_against_oracle():
+    """simple.pov-sized AA frame: 640x480 at 4 samples per pixel on a mesh scene."""
+    sd = ra.SceneData.load(os.path.join(GOLDEN, "scenes", "bunny.npz"))
+    with ra.Scene(sd) as sc:
+        frame, st = sc.render(640, 480, 4, abi.RT_PHONG, abi.RT_JITTER_HASH, seed=11)
+    osc = orclib.OracleScene(sd)
+    ref = osc.render(640, 480, 4, abi.RT_PHONG, abi.RT_JITTER_HASH, 11, want_samples=False, want_primary=False)
+    osc.close()
+    diff = np.abs(frame[:, :, :3].astype(int) - ref["rgba"][:, :, :3].astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.999
+    assert st["rays_primary"] == 640 * 480 * 4

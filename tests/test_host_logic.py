@@ -1,0 +1,212 @@
+"""CPU-side checks of the product: the C-ABI library, the host BVH builder, the parser and the TGA writer.
+
+No compute entry point is called (there is no GPU here); what runs is host code of libraytracer_amd.so,
+compared against the oracle and the committed fixtures.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orclib
+import raytracer_amd as ra
+from raytracer_amd import abi, tiles
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+ALL_SCENES = sorted(os.path.splitext(f)[0] for f in os.listdir(os.path.join(GOLD, "scenes")))
+
+
+def scene(name):
+    return ra.SceneData.load(os.path.join(GOLD, "scenes", name + ".npz"))
+
+
+# ------------------------------------------------------------------ library
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z_0-9]+|launch_kernel)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = abi.load_library()
+    declared = set(declared_functions("raytracer_amd.h"))
+    assert "launch_kernel" in declared_functions("raytracer_tokens.h")      # the C++ drop-in header declares only this one
+    declared.add("launch_kernel")
+    assert declared == set(abi.EXPORTED_SYMBOLS), declared ^ set(abi.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(abi.Camera) == 48
+    assert C.sizeof(abi.RenderParams) == 40
+    assert C.sizeof(abi.SceneInfo) == 48
+    # rt_stats: 8 u64, 9 floats, 2 i32 (44 bytes -> padded to 48), 12 u64
+    assert C.sizeof(abi.Stats) == 8 * 8 + 48 + 12 * 8
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        abi.load_library(str(tmp_path / "libraytracer_amd.so"))
+
+
+def test_render_without_device_is_an_error():
+    if ra.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(ra.RaytracerError) as e:
+        ra.Scene(scene("simple"))
+    assert e.value.code == abi.RT_ERR_NO_DEVICE
+    with ra.Scene(scene("simple"), host_only=True) as sc:
+        with pytest.raises(ra.RaytracerError) as e:
+            sc.render(32, 32)
+        assert e.value.code == abi.RT_ERR_NO_DEVICE
+
+
+def test_launch_kernel_mirror_rejects_bad_sample_count(capsys):
+    out = np.full(16 * 16 * 4, 7, np.uint8)
+    ra.launch_kernel(scene("simple"), ra.PHONG, 16, 16, out, 3)
+    assert "Invalid sample count: 3" in capsys.readouterr().out        # kernel.cu:707-712
+    assert (out == 7).all()
+
+
+# ---------------------------------------------------------------------- BVH
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_host_bvh_equals_oracle_bvh(name):
+    sd = scene(name)
+    osc = orclib.OracleScene(sd)
+    try:
+        with ra.Scene(sd, host_only=True) as sc:
+            info = sc.info()
+            nodes, order = sc.bvh()
+        onodes, oroot, odepth = osc.flatten()
+        assert info["n_bvh_prims"] == osc.n_bvh_prims and info["n_planes"] == osc.n_planes
+        assert info["root"] == oroot and info["tree_depth"] == odepth
+        assert order.tolist() == osc.leaf_order().tolist()
+        assert nodes.tobytes() == onodes.tobytes()
+    finally:
+        osc.close()
+
+
+def test_bvh_shape_invariants():
+    sd = scene("iceBot")
+    with ra.Scene(sd, host_only=True) as sc:
+        info = sc.info()
+        nodes, order = sc.bvh()
+    n = info["n_bvh_prims"]
+    assert info["n_nodes"] == n - 1 and sorted(order.tolist()) == list(range(n))
+    leaves = [~c for c in np.concatenate([nodes["left"], nodes["right"]]).tolist() if c < 0]
+    assert sorted(leaves) == list(range(n))
+    inner = [c for c in np.concatenate([nodes["left"], nodes["right"]]).tolist() if c >= 0]
+    assert sorted(inner) == list(range(1, n - 1))          # pre-order numbering, root = 0, every node referenced once
+    assert (nodes["lmin"] <= nodes["lmax"]).all() and (nodes["rmin"] <= nodes["rmax"]).all()
+
+
+def test_degenerate_scenes_build():
+    empty = ra.SceneData()
+    empty.camera = scene("simple").camera
+    with ra.Scene(empty, host_only=True) as sc:
+        assert sc.info()["n_nodes"] == 0 and sc.info()["root"] == -2 ** 31
+    one = scene("simple")
+    assert one.n_bvh_prims == 1
+    with ra.Scene(one, host_only=True) as sc:
+        assert sc.info()["n_nodes"] == 0 and sc.info()["root"] == ~0
+
+
+# ------------------------------------------------------------------- parser
+@pytest.mark.parametrize("name", ["grammar_mix", "cr_only"])
+def test_parser_on_committed_pov(name):
+    got = ra.parse_pov(os.path.join(GOLD, "pov", name + ".pov"))
+    want = ra.SceneData.load(os.path.join(GOLD, "pov", name + ".expected.npz"))
+    assert got.equals(want)
+
+
+@pytest.mark.parametrize("name", ["bad_object", "bad_vector"])
+def test_parser_rejects_what_the_reference_rejects(name):
+    with pytest.raises(ra.RaytracerError) as e:
+        ra.parse_pov(os.path.join(GOLD, "pov", name + ".pov"))
+    assert e.value.code == abi.RT_ERR_PARSE
+
+
+def test_parser_missing_file():
+    with pytest.raises(ra.RaytracerError) as e:
+        ra.parse_pov(os.path.join(GOLD, "pov", "does_not_exist.pov"))
+    assert e.value.code == abi.RT_ERR_IO
+
+
+@pytest.mark.skipif(not os.path.isdir(orclib.REFERENCE_DIR), reason="reference checkout not present")
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_parser_on_reference_scenes(name):
+    """The scene fixtures were made by the reference's own parser; ours must produce the same bytes."""
+    got = ra.parse_pov(os.path.join(orclib.REFERENCE_DIR, name + ".pov"))
+    assert got.equals(scene(name))
+
+
+def test_scene_round_trip(tmp_path):
+    sd = scene("cornell")
+    p = str(tmp_path / "s.npz")
+    sd.save(p)
+    assert ra.SceneData.load(p).equals(sd)
+    desc, keep = sd.to_desc()
+    assert ra.SceneData.from_desc(desc).equals(sd)
+
+
+# ---------------------------------------------------------------------- TGA
+def test_tga_bytes(tmp_path):
+    rng = np.random.default_rng(3)
+    w, h = 37, 21
+    frame = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    frame[0, :, 0] = np.arange(w) * 6 % 256
+    frame.reshape(-1, 4)[:256, 1] = np.arange(256)           # every byte value goes through the channel map
+    path = str(tmp_path / "a.tga")
+    ra.write_tga(path, frame)
+    b = open(path, "rb").read()
+    assert len(b) == 18 + w * h * 3
+    assert list(b[:18]) == [0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, w & 255, w >> 8, h & 255, h >> 8, 24, 0]
+    lut = np.array([int(((k / 255.0) / 1.0) * 255) for k in range(256)], np.uint8)    # Image.cpp:77-101 in doubles
+    want = lut[frame[:, :, 2::-1]]                                                       # BGR
+    assert np.frombuffer(b, np.uint8, offset=18).reshape(h, w, 3).tobytes() == want.tobytes()
+    if orclib.have_ref():
+        path2 = str(tmp_path / "b.tga")
+        orclib.ref().ref_write_tga(path2.encode(), w, h, frame.ctypes.data)
+        assert open(path2, "rb").read() == b
+
+
+def test_tga_bad_arguments(tmp_path):
+    with pytest.raises(ra.RaytracerError):
+        ra.write_tga(str(tmp_path / "no_such_dir" / "x.tga"), np.zeros((2, 2, 4), np.uint8))
+
+
+# -------------------------------------------------------------------- tiles
+@pytest.mark.parametrize("wh", [(1920, 1080), (640, 480), (33, 31), (1, 1), (32, 32), (100, 7)])
+def test_tile_partition(wh):
+    w, h = wh
+    tx, ty = tiles.tile_grid(w, h)
+    assert ra.tile_count(w, h, 0, 1) == tx * ty
+    for world in (1, 2, 3, 8):
+        seen = []
+        for r in range(world):
+            mine = tiles.tiles_of(w, h, r, world)
+            assert ra.tile_count(w, h, r, world) == len(mine) <= tiles.part_tiles(w, h, world)
+            seen += mine
+        assert sorted(seen) == list(range(tx * ty))
+    assert ra.tile_count(w, h, tx * ty, 1) == 0 and ra.tile_count(0, h, 0, 1) == 0
+
+
+def test_untile_host_inverts_the_tile_layout():
+    rng = np.random.default_rng(5)
+    w, h, world = 100, 70, 3
+    frame = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    stride = tiles.part_bytes(w, h, world)
+    parts = np.zeros(world * stride, np.uint8)
+    tx, _ = tiles.tile_grid(w, h)
+    for r in range(world):
+        for k, tile in enumerate(tiles.tiles_of(w, h, r, world)):
+            x0, y0 = (tile % tx) * 32, (tile // tx) * 32
+            blk = np.zeros((32, 32, 4), np.uint8)
+            sub = frame[y0:y0 + 32, x0:x0 + 32]
+            blk[:sub.shape[0], :sub.shape[1]] = sub
+            parts[r * stride + k * 4096: r * stride + (k + 1) * 4096] = blk.reshape(-1)
+    assert (tiles.untile_host(parts, stride, world, w, h) == frame).all()
