@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Condenses the raw rocprofv3 output of profiles/collect.sh into the small files kept under profiles/.
+
+  <tag>_bench.json            the bench.py line of the same run
+  <tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats: per-kernel calls / total / average ns
+  <tag>_pmc_summary.json      per-kernel sums and per-launch averages of the counters of each --pmc pass
+  traffic_trace_kernel.json   HBM-side bytes per launch of the dominant kernel (the closest-hit
+                              traversal): FETCH_SIZE doubled as the gfx950 note on that counter says
+                              (it tallies 128-byte requests as 64), plus WRITE_SIZE as reported; bench.py
+                              reads it into roofline.traffic
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DOMINANT = "k_trace<0"
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+def pmc_table(path):
+    """{kernel: {counter: [sum, launches]}} from one counter_collection.csv (one row per dispatch x counter)."""
+    out = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            cell = out[short(row["Kernel_Name"])][row["Counter_Name"]]
+            cell[0] += float(row["Counter_Value"])
+            cell[1] += 1
+    return out
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    if os.path.exists(os.path.join(src, "bench.json")):
+        shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+    for p in glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(p, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    summary = {}
+    for pas in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_l2"):
+        files = glob.glob(os.path.join(src, pas, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        tab = pmc_table(files[0])
+        summary[pas] = {k: {c: {"sum": v[0], "launches": v[1], "per_launch": v[0] / max(1, v[1])} for c, v in cs.items()}
+                        for k, cs in tab.items() if k.startswith("k_")}
+    json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    fetch = write = None
+    for k, cs in summary.get("pmc_fetch", {}).items():
+        if k.startswith(DOMINANT) and "FETCH_SIZE" in cs:
+            fetch = cs["FETCH_SIZE"]["per_launch"]
+    for k, cs in summary.get("pmc_write", {}).items():
+        if k.startswith(DOMINANT) and "WRITE_SIZE" in cs:
+            write = cs["WRITE_SIZE"]["per_launch"]
+    if fetch is not None:
+        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB
+        fetch_b = fetch * 1024 * 2
+        write_b = (write or 0.0) * 1024
+        json.dump({"kernel": DOMINANT + ", false>", "tag": tag,
+                   "fetch_size_kib_per_launch_raw": fetch, "write_size_kib_per_launch_raw": write,
+                   "correction": "FETCH_SIZE x2 (gfx950 tallies 128-byte requests as 64 bytes); WRITE_SIZE as reported; "
+                                 "16-byte-per-lane gathers of 64-byte records are not the calibrated streaming pattern, "
+                                 "so the absolute figure is indicative",
+                   "hbm_bytes_per_launch": int(fetch_b + write_b)},
+                  open(os.path.join(dst, "traffic_trace_kernel.json"), "w"), indent=1)
+    print(open(os.path.join(dst, f"{tag}_bench.json")).read() if os.path.exists(os.path.join(dst, f"{tag}_bench.json")) else "no bench line")
+
+
+if __name__ == "__main__":
+    main()

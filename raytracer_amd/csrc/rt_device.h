@@ -101,8 +101,9 @@ __device__ __forceinline__ bool in_div_range(float v)
 /* per-ray constants of the slab test */
 struct RayCtx {
    Ray r;
-   float yx, yy, yz;      /* RN(1/d) per axis */
-   bool fast;             /* no axis-parallel component and every value inside rt_div's safe range */
+   float yx, yy, yz;      /* RN(1/d) per axis (unused on a parallel axis) */
+   unsigned par;          /* bit k set: axis k is "parallel", |d_k| < EPSILON (GeometryUtil.h:16,23,30) */
+   bool fast;             /* every value the short box test divides is inside rt_div's safe range */
 };
 
 __device__ __forceinline__ RayCtx make_ctx(const Ray &r)
@@ -110,10 +111,12 @@ __device__ __forceinline__ RayCtx make_ctx(const Ray &r)
    RayCtx c;
    c.r = r;
    c.yx = 1.0f / r.d.x; c.yy = 1.0f / r.d.y; c.yz = 1.0f / r.d.z;
-   /* |d| >= 2^-40 alone would admit the reference's "parallel" axes (|d| < 1e-4, GeometryUtil.h:16,23,30) */
-   bool par = is_zero(r.d.x) || is_zero(r.d.y) || is_zero(r.d.z);
-   c.fast = !par && (r.o.x == 0.0f || in_div_range(r.o.x)) && (r.o.y == 0.0f || in_div_range(r.o.y)) &&
-            (r.o.z == 0.0f || in_div_range(r.o.z)) && in_div_range(r.d.x) && in_div_range(r.d.y) && in_div_range(r.d.z);
+   bool px = is_zero(r.d.x), py = is_zero(r.d.y), pz = is_zero(r.d.z);
+   c.par = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u);
+   /* a parallel axis is never divided by, so only the other axes' directions have to be in range */
+   c.fast = (r.o.x == 0.0f || in_div_range(r.o.x)) && (r.o.y == 0.0f || in_div_range(r.o.y)) &&
+            (r.o.z == 0.0f || in_div_range(r.o.z)) && (px || in_div_range(r.d.x)) && (py || in_div_range(r.d.y)) &&
+            (pz || in_div_range(r.d.z));
    return c;
 }
 
@@ -147,12 +150,17 @@ __device__ __forceinline__ float slab_literal(const Ray &r, float mnx, float mny
    return miss ? -1.0f : res;
 }
 
-/* boxIntersect for a ray with no parallel axis and in-range values: same bits, fewer instructions.
- *  - the three quotient pairs are never NaN, so min/max order them exactly as the reference's swaps do
- *    and max3/min3 equal its mymax/mymin chains;
- *  - the origin is strictly inside the box exactly when every axis has lo < 0 < hi, i.e. when
- *    tBiggestMin < 0 < tSmallestMax (a difference of two floats keeps its sign, and the quotient of an
- *    in-range pair cannot underflow), which replaces the six coordinate comparisons. */
+/* boxIntersect for a ray with in-range values: same bits, fewer instructions.
+ *  - the quotient pairs of the non-parallel axes are never NaN, so min/max order them exactly as the
+ *    reference's swaps do and max3/min3 equal its mymax/mymin chains;
+ *  - the origin is strictly inside the box on such an axis exactly when lo < 0 < hi (a difference of
+ *    two floats keeps its sign, and the quotient of an in-range pair cannot underflow), so "inside"
+ *    is tBiggestMin < 0 < tSmallestMax instead of six coordinate comparisons;
+ *  - PAR = true also takes rays with parallel axes: such an axis contributes the reference's
+ *    -FLT_MAX / FLT_MAX pair (neutral in max3/min3), a miss when the origin is outside the slab, and
+ *    its strict coordinate test to "inside".  Whatever rt_div made of the tiny or zero direction is
+ *    discarded by the selects.  PAR = false is the same function for a wave that holds no such ray. */
+template <bool PAR>
 __device__ __forceinline__ float slab_fast(const RayCtx &c, float mnx, float mny, float mnz,
                                            float mxx, float mxy, float mxz)
 {
@@ -160,16 +168,24 @@ __device__ __forceinline__ float slab_fast(const RayCtx &c, float mnx, float mny
    float x1 = rt_div(mnx - r.o.x, r.d.x, c.yx), x2 = rt_div(mxx - r.o.x, r.d.x, c.yx);
    float y1 = rt_div(mny - r.o.y, r.d.y, c.yy), y2 = rt_div(mxy - r.o.y, r.d.y, c.yy);
    float z1 = rt_div(mnz - r.o.z, r.d.z, c.yz), z2 = rt_div(mxz - r.o.z, r.d.z, c.yz);
-   float A = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
-   float B = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
-   return (A < 0.0f && B > 0.0f) ? B : (A < B ? A : -1.0f);
-}
-
-template <bool FAST>
-__device__ __forceinline__ float slab_test(const RayCtx &c, float mnx, float mny, float mnz,
-                                           float mxx, float mxy, float mxz)
-{
-   return FAST ? slab_fast(c, mnx, mny, mnz, mxx, mxy, mxz) : slab_literal(c.r, mnx, mny, mnz, mxx, mxy, mxz);
+   float xl = fminf(x1, x2), xh = fmaxf(x1, x2);
+   float yl = fminf(y1, y2), yh = fmaxf(y1, y2);
+   float zl = fminf(z1, z2), zh = fmaxf(z1, z2);
+   bool miss = false, strict = true;
+   if (PAR) {
+      bool px = (c.par & 1u) != 0, py = (c.par & 2u) != 0, pz = (c.par & 4u) != 0;
+      xl = px ? -FLT_MAX : xl; xh = px ? FLT_MAX : xh;
+      yl = py ? -FLT_MAX : yl; yh = py ? FLT_MAX : yh;
+      zl = pz ? -FLT_MAX : zl; zh = pz ? FLT_MAX : zh;
+      miss = (px && (r.o.x < mnx || r.o.x > mxx)) || (py && (r.o.y < mny || r.o.y > mxy)) ||
+             (pz && (r.o.z < mnz || r.o.z > mxz));
+      strict = (!px || (r.o.x > mnx && r.o.x < mxx)) && (!py || (r.o.y > mny && r.o.y < mxy)) &&
+               (!pz || (r.o.z > mnz && r.o.z < mxz));
+   }
+   float A = fmaxf(fmaxf(xl, yl), zl);
+   float B = fminf(fminf(xh, yh), zh);
+   float res = (A < 0.0f && B > 0.0f && strict) ? B : (A < B ? A : -1.0f);
+   return miss ? -1.0f : res;
 }
 
 /* Sphere::intersects, Sphere.h:42-66 (ray already in object space) */

@@ -37,6 +37,7 @@
 #include <cstring>
 #include <deque>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "rt_common.h"
@@ -310,9 +311,11 @@ __device__ __forceinline__ void plane_scan(const DScene &sc, const Ray &ray, flo
  * and refills idle lanes from the queue when RT_REFILL_IDLE of them are free.  A ray's own sequence
  * of operations is exactly that of the reference loop; only the interleaving between rays differs.
  *
- * Only rays the short box test is exact for run here (no axis-parallel direction, values in range:
- * RayCtx::fast).  The others -- typically the one pixel column or row whose direction has an exact
- * zero -- are appended to `slow_list` and traced by k_trace_slow with the literal arithmetic. */
+ * Only rays the short box test is exact for run here (values inside the exact-division range:
+ * RayCtx::fast); that is every ray of an ordinary scene.  A wave that holds a ray with an axis-parallel
+ * direction component -- typically from the one pixel column or row through the view axis -- runs the
+ * variant of the node step that handles such axes, all other waves the shorter one.  Out-of-range rays
+ * are appended to `slow_list` and traced by k_trace_slow with the literal arithmetic. */
 template <int OUT, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays, unsigned long long n, Hit *hits,
                                                     unsigned char *flags, unsigned long long *next,
@@ -326,8 +329,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
 
    bool active = false;
    bool exhausted = false;             /* wave-uniform: the queue has no more rays */
+   bool wave_par = false;              /* wave-uniform: some lane may hold a ray with a parallel axis */
    RayCtx c;
-   c.r.o = mk3(0, 0, 0); c.r.d = mk3(1, 1, 1); c.yx = c.yy = c.yz = 1.0f; c.fast = true;
+   c.r.o = mk3(0, 0, 0); c.r.d = mk3(1, 1, 1); c.yx = c.yy = c.yz = 1.0f; c.par = 0; c.fast = true;
    float t = FLT_MAX, toBeat = -FLT_MAX;
    int closest = -1, cur = 0, sp = 0;
    unsigned idx = 0;
@@ -351,6 +355,30 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
          if (e.dist < t) { cur = e.child; found = true; break; }
       }
       if (!found) finish(false);
+   };
+
+   /* one node step of this lane (kernel.cu:136-158); PAR: some lane of the wave has a parallel axis */
+   auto node_step = [&](auto par_tag) {
+      constexpr bool PAR = decltype(par_tag)::value;
+      /* 56 of the record's 64 bytes: two boxes and the two child references */
+      const char *rec = reinterpret_cast<const char *>(sc.nodes) + ((unsigned)cur << 6);
+      float4 a = *reinterpret_cast<const float4 *>(rec);
+      float4 b = *reinterpret_cast<const float4 *>(rec + 16);
+      float4 cc = *reinterpret_cast<const float4 *>(rec + 32);
+      int2 ch = *reinterpret_cast<const int2 *>(rec + 48);
+      if (COUNT) nv++;
+      float left = slab_fast<PAR>(c, a.x, a.y, a.z, a.w, b.x, b.y);
+      float right = slab_fast<PAR>(c, b.z, b.w, cc.x, cc.y, cc.z, cc.w);
+      /* kernel.cu:148-158 as predicates: right first on `<=`, the other child deferred if it is ahead too */
+      bool aL = above_zero(left), aR = above_zero(right);
+      bool goR = aR && (right <= left || !aL) && right < t;
+      bool goL = !goR && aL && (left <= right || !aR) && left < t;
+      if ((goR && aL) || (goL && aR)) {
+         StackEntry e; e.child = goR ? ch.x : ch.y; e.dist = goR ? left : right;
+         stack[sp * stride] = e; sp++;
+      }
+      if (goR || goL) cur = goR ? ch.y : ch.x;
+      else pop();
    };
 
    /* Every wave reaches its exit in a bounded number of steps: a ray visits each node at most once per
@@ -387,6 +415,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
             }
          }
          m_active = __ballot(active);
+         wave_par = __ballot(active && c.par != 0) != 0;
       }
       if (m_active == 0) {
          if (exhausted) break;
@@ -399,25 +428,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
          if (__ballot(in_node) == 0) break;
          if (COUNT) { wn++; if (active) ray_steps++; }
          if (in_node) {
-            /* 56 of the record's 64 bytes: two boxes and the two child references */
-            const char *rec = reinterpret_cast<const char *>(sc.nodes) + ((unsigned)cur << 6);
-            float4 a = *reinterpret_cast<const float4 *>(rec);
-            float4 b = *reinterpret_cast<const float4 *>(rec + 16);
-            float4 cc = *reinterpret_cast<const float4 *>(rec + 32);
-            int2 ch = *reinterpret_cast<const int2 *>(rec + 48);
-            if (COUNT) nv++;
-            float left = slab_fast(c, a.x, a.y, a.z, a.w, b.x, b.y);
-            float right = slab_fast(c, b.z, b.w, cc.x, cc.y, cc.z, cc.w);
-            /* kernel.cu:148-158 as predicates: right first on `<=`, the other child deferred if it is ahead too */
-            bool aL = above_zero(left), aR = above_zero(right);
-            bool goR = aR && (right <= left || !aL) && right < t;
-            bool goL = !goR && aL && (left <= right || !aR) && left < t;
-            if ((goR && aL) || (goL && aR)) {
-               StackEntry e; e.child = goR ? ch.x : ch.y; e.dist = goR ? left : right;
-               stack[sp * stride] = e; sp++;
-            }
-            if (goR || goL) cur = goR ? ch.y : ch.x;
-            else pop();
+            if (wave_par) node_step(std::true_type());
+            else node_step(std::false_type());
          }
       }
       /* ---- leaf step ---- */

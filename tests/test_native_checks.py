@@ -3,7 +3,8 @@
 Both programs compare the shortcut with the reference's literal arithmetic bit for bit:
   exact_div_hard_cases.c  every operand pair whose quotient is close enough to a rounding boundary
                           for the 3-operation division to be able to misround (exhaustive)
-  slab_short_form.c       the short box test against boxIntersect (GeometryUtil.h:9-51), randomised
+  slab_short_form.c       the short box test against boxIntersect (GeometryUtil.h:9-51), randomised, with and
+                          without axis-parallel direction components
 """
 import os
 import subprocess
@@ -39,3 +40,4 @@ def test_short_slab_form(tmp_path):
                     os.path.join(HERE, "native", "slab_short_form.c"), "-o", str(exe), "-lm"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     assert "bad=0" in out and "bitdiff(incl zero sign)=0" in out, out
+    assert int(out.split("with_parallel_axis=")[1].split()[0]) > 1_000_000, out
