@@ -44,6 +44,7 @@
 #include "rt_device.h"
 
 #define RT_BLOCK 256
+#define RT_RING 4            /* chunks of a frame that may be in flight at once (each owns a slice of the arena) */
 
 /* ======================================================================= */
 /* device-side views                                                        */
@@ -92,7 +93,7 @@ struct SpawnRec {
 enum { ST_SHADOW_TRACED = 0, ST_SHADOW_SKIPPED, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES, ST_PRIMARY,
        ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
        ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_WAVE_NODE_STEPS_SHADOW, ST_WAVE_LEAF_STEPS_SHADOW,
-       ST_ABORTED, ST_MAX_RAY_STEPS, ST_MAX_RAY_STEPS_SHADOW, ST_COUNT };
+       ST_ABORTED, ST_MAX_RAY_STEPS, ST_MAX_RAY_STEPS_SHADOW, ST_OVERFLOW, ST_NODES_PER_PRIMARY_X16, ST_COUNT };
 
 /* Statistics counters are replicated RT_STAT_REPL times (blocks spread over the replicas, the host
  * sums them) and bumped once per wave, so that counting does not serialise the kernels on one word. */
@@ -243,11 +244,56 @@ __device__ __noinline__ bool tie_prefers_new(const rt_dev_prim *prims, const rt_
 struct StackEntry { int child; float dist; };
 extern __shared__ StackEntry lds_stack[];
 
-enum { OUT_HIT = 0, OUT_FLAG = 1 };
+/* k_trace: persistent-thread closest-hit / any-hit over a ray queue.
+ *
+ * Lane state is one ray: (ctx, t, closest, cur, sp).  cur >= 0 is an internal node, cur < 0 a leaf
+ * (~cur = primitive).  The wave alternates between bursts of
+ *   node steps  -- every lane at an internal node tests the two child boxes of its node
+ *                  (kernel.cu:136-158) and descends / defers / pops,
+ * and one
+ *   leaf step   -- every lane at a leaf intersects its primitive (kernel.cu:104-134) and pops,
+ * and refills idle lanes from the queue when RT_REFILL_IDLE of them are free.  A ray's own sequence
+ * of operations is exactly that of the reference loop; only the interleaving between rays differs.
+ *
+ * Three variants of the node step, chosen per wave (uniform branch): the short box test for waves
+ * whose rays are all ordinary, the short test with parallel-axis handling when some lane holds a ray
+ * with an axis-parallel direction component (typically from the one pixel column or row through the
+ * view axis), and the reference's literal arithmetic when some lane holds a ray outside the exact
+ * division's range (RayCtx::fast false; no ordinary scene has one).
+ *
+ * OUT_HIT    writes the closest hit of ray i to hits[i].
+ * OUT_FLAG   shadow feelers: writes isInShadow (kernel.cu:206) to flags[valid - 1].
+ * OUT_CHAIN  the whole bounce tree of the first n rays in one launch: a finished ray's reflection and
+ *            refraction rays (getReflection / getRefraction, kernel.cu:209-276, guarded as in
+ *            kernel.cu:361-371) are appended to the same queue behind the primaries (one atomic per wave
+ *            for the indices) and traced BY THE WAVE THAT SPAWNED THEM: their indices go onto a per-wave
+ *            last-in-first-out list in LDS which idle lanes drain before they fetch new primaries.  No
+ *            data is handed between waves, so there is nothing to wait for and every wave's exit is
+ *            its own: primaries dry, list empty, lanes idle.  valid = depth level + 1. */
+enum { OUT_HIT = 0, OUT_FLAG = 1, OUT_CHAIN = 2 };
 
 #define RT_STEP_CAP (1ULL << 28)
 #define RT_REFILL_IDLE 20   /* pull new rays once this many lanes of the wave are idle */
 #define RT_NODE_BURST 6     /* node steps between two leaf steps / refill checks */
+#define RT_LIFO_CAP 512     /* spawned rays a wave can hold back; 64 lanes x 5 spawning levels = 320 is the most a
+                             * newest-first drain leaves waiting */
+
+struct TraceArgs {
+   QRay *rays;                  /* the queue; OUT_CHAIN appends spawned rays behind the first n */
+   unsigned long long n;        /* rays to fetch (OUT_CHAIN: the primaries) */
+   const unsigned *n_dev;       /* when non-null, n is read from here instead */
+   Hit *hits;                   /* OUT_HIT, OUT_CHAIN */
+   unsigned char *flags;        /* OUT_FLAG */
+   unsigned long long *next;    /* this launch's zeroed fetch counter */
+   unsigned long long *stats;
+   int stat_base;
+   int stack_depth;             /* entries per lane of the traversal stack (the LDS behind it is the OUT_CHAIN list) */
+   /* OUT_CHAIN */
+   SpawnRec *recs;
+   unsigned *tail;              /* next free queue entry; starts at n */
+   unsigned cap;                /* entries the queue has room for */
+   int max_rec;
+};
 
 __device__ __forceinline__ QRay load_qray_rec(const QRay *q, unsigned long long i)
 {
@@ -255,6 +301,18 @@ __device__ __forceinline__ QRay load_qray_rec(const QRay *q, unsigned long long 
    float4 a = p[0], b = p[1];
    QRay r;
    r.ox = a.x; r.oy = a.y; r.oz = a.z; r.to_beat = a.w; r.dx = b.x; r.dy = b.y; r.dz = b.z; r.valid = __float_as_int(b.w);
+   return r;
+}
+/* the same entry read at agent scope, past the CU's vector cache: for entries this kernel wrote itself */
+__device__ __forceinline__ QRay load_qray_written(QRay *q, unsigned long long i)
+{
+   unsigned *p = reinterpret_cast<unsigned *>(q + i);
+   unsigned w[8];
+#pragma unroll
+   for (int k = 0; k < 8; k++) w[k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   QRay r;
+   r.ox = __uint_as_float(w[0]); r.oy = __uint_as_float(w[1]); r.oz = __uint_as_float(w[2]); r.to_beat = __uint_as_float(w[3]);
+   r.dx = __uint_as_float(w[4]); r.dy = __uint_as_float(w[5]); r.dz = __uint_as_float(w[6]); r.valid = (int)w[7];
    return r;
 }
 __device__ __forceinline__ void store_qray(QRay *q, unsigned long long i, F3 o, F3 d, float to_beat, int valid)
@@ -300,40 +358,68 @@ __device__ __forceinline__ void plane_scan(const DScene &sc, const Ray &ray, flo
    }
 }
 
-/* k_trace: persistent-thread closest-hit / any-hit over a ray queue.
- *
- * Lane state is one ray: (ctx, t, closest, cur, sp).  cur >= 0 is an internal node, cur < 0 a leaf
- * (~cur = primitive).  The wave alternates between bursts of
- *   node steps  -- every lane at an internal node tests the two child boxes of its node
- *                  (kernel.cu:136-158) and descends / defers / pops,
- * and one
- *   leaf step   -- every lane at a leaf intersects its primitive (kernel.cu:104-134) and pops,
- * and refills idle lanes from the queue when RT_REFILL_IDLE of them are free.  A ray's own sequence
- * of operations is exactly that of the reference loop; only the interleaving between rays differs.
- *
- * Only rays the short box test is exact for run here (values inside the exact-division range:
- * RayCtx::fast); that is every ray of an ordinary scene.  A wave that holds a ray with an axis-parallel
- * direction component -- typically from the one pixel column or row through the view axis -- runs the
- * variant of the node step that handles such axes, all other waves the shorter one.  Out-of-range rays
- * are appended to `slow_list` and traced by k_trace_slow with the literal arithmetic. */
+/* The reflection and refraction rays of a hit (getReflection kernel.cu:214-216, getRefraction
+ * kernel.cu:239-257).  Out of line and fed by value, like the tie rule, so that the traversal loop's
+ * registers are not sized by it. */
+struct BounceRays { float ro[3], rd[3], to[3], td[3]; int want_refl, want_refr; };
+__device__ __noinline__ BounceRays bounce_rays(const rt_dev_prim *prims, const rt_dev_xform *xforms, const rt_dev_shade *shades,
+                                               const rt_dev_plane *planes, int n_prims,
+                                               float ox, float oy, float oz, float dx, float dy, float dz, int prim, float t,
+                                               float m_refl, float m_refr, float m_ior)
+{
+   BounceRays b;
+   b.want_refl = b.want_refr = 0;
+   for (int k = 0; k < 3; k++) b.ro[k] = b.rd[k] = b.to[k] = b.td[k] = 0.0f;
+   Ray ray; ray.o = mk3(ox, oy, oz); ray.d = mk3(dx, dy, dz);
+   F3 P = ray_point(ray, t);                                           /* kernel.cu:340 */
+   F3 normal;
+   if (prim >= n_prims) { const rt_dev_plane &pl = planes[prim - n_prims]; normal = mk3(pl.wsN[0], pl.wsN[1], pl.wsN[2]); }
+   else normal = prim_normal_at(prims, xforms, shades, prim, ray, t);   /* kernel.cu:342 */
+   F3 eye = normalize3(-ray.d);                                        /* kernel.cu:344 */
+   if (m_refl > 0.0f) {
+      F3 d = (2.0f * dot3(normal, eye)) * normal - eye;
+      F3 o = P + RT_BIG_EPS * d;
+      b.ro[0] = o.x; b.ro[1] = o.y; b.ro[2] = o.z; b.rd[0] = d.x; b.rd[1] = d.y; b.rd[2] = d.z;
+      b.want_refl = 1;
+   }
+   if (m_refr > 0.0f) {
+      float n1, n2; F3 refrNorm; F3 dd = -eye;
+      if (less_than(dot3(eye, normal), 0.0f)) { n1 = m_ior; n2 = RT_AIR_IOR; refrNorm = -normal; }
+      else { n1 = RT_AIR_IOR; n2 = m_ior; refrNorm = normal; }
+      float dDotN = dot3(dd, refrNorm);
+      float nr = n1 / n2;
+      float disc = 1.0f - nr * nr * (1.0f - dDotN * dDotN);
+      if (disc > 0.0f) {
+         F3 d = nr * (dd - refrNorm * dDotN) - refrNorm * sqrtf(disc);
+         F3 o = P + RT_BIG_EPS * d;
+         b.to[0] = o.x; b.to[1] = o.y; b.to[2] = o.z; b.td[0] = d.x; b.td[1] = d.y; b.td[2] = d.z;
+         b.want_refr = 1;
+      }
+   }
+   return b;
+}
+
 template <int OUT, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays, unsigned long long n, Hit *hits,
-                                                    unsigned char *flags, unsigned long long *next,
-                                                    unsigned *slow_list, unsigned *slow_count,
-                                                    unsigned long long *stats, int stat_base)
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, TraceArgs a)
 {
    StackEntry *stack = lds_stack + threadIdx.x;
    const int stride = RT_BLOCK;
    const unsigned lane = __lane_id();
    const unsigned long long below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+   unsigned *lifo = reinterpret_cast<unsigned *>(lds_stack + (size_t)RT_BLOCK * a.stack_depth) + (threadIdx.x >> 6) * RT_LIFO_CAP;
+   int lifo_count = 0;                 /* wave-uniform */
+   const unsigned long long n = a.n_dev ? (unsigned long long)*a.n_dev : a.n;
+   unsigned long long *const stats = a.stats;
 
    bool active = false;
-   bool exhausted = false;             /* wave-uniform: the queue has no more rays */
+   bool pend = false;                  /* OUT_CHAIN: finished, its bounce rays not spawned yet */
+   bool exhausted = n == 0;            /* wave-uniform: the queue has no more rays to fetch */
    bool wave_par = false;              /* wave-uniform: some lane may hold a ray with a parallel axis */
+   bool wave_lit = false;              /* wave-uniform: some lane holds a ray the short box test is not valid for */
    RayCtx c;
    c.r.o = mk3(0, 0, 0); c.r.d = mk3(1, 1, 1); c.yx = c.yy = c.yz = 1.0f; c.par = 0; c.fast = true;
    float t = FLT_MAX, toBeat = -FLT_MAX;
-   int closest = -1, cur = 0, sp = 0;
+   int closest = -1, cur = 0, sp = 0, tag = 0;
    unsigned idx = 0;
    unsigned nv = 0, np = 0, nt = 0, wn = 0, wl = 0;
    unsigned ray_steps = 0, max_ray_steps = 0;   /* COUNT only: wave steps this ray has been in flight */
@@ -342,9 +428,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
    auto finish = [&](bool early) {
       if (COUNT) { max_ray_steps = ray_steps > max_ray_steps ? ray_steps : max_ray_steps; }
       if (!early) plane_scan(sc, c.r, t, closest);
-      if (OUT == OUT_HIT) { Hit h; h.prim = closest; h.t = t; hits[idx] = h; }
-      else flags[idx] = less_than(t, toBeat) ? 1 : 0;            /* kernel.cu:206 */
+      if (OUT == OUT_FLAG) a.flags[tag - 1] = less_than(t, toBeat) ? 1 : 0;            /* kernel.cu:206 */
+      else { Hit h; h.prim = closest; h.t = t; a.hits[idx] = h; }
       active = false;
+      if (OUT == OUT_CHAIN) pend = true;
    };
    /* pop deferred siblings until one is still closer than t (kernel.cu:160-186); none left = done */
    auto pop = [&]() {
@@ -356,19 +443,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
       }
       if (!found) finish(false);
    };
-
-   /* one node step of this lane (kernel.cu:136-158); PAR: some lane of the wave has a parallel axis */
-   auto node_step = [&](auto par_tag) {
-      constexpr bool PAR = decltype(par_tag)::value;
+   /* one node step of this lane (kernel.cu:136-158) */
+   auto node_step = [&](auto variant_tag) {
+      constexpr int VARIANT = decltype(variant_tag)::value;
       /* 56 of the record's 64 bytes: two boxes and the two child references */
       const char *rec = reinterpret_cast<const char *>(sc.nodes) + ((unsigned)cur << 6);
-      float4 a = *reinterpret_cast<const float4 *>(rec);
-      float4 b = *reinterpret_cast<const float4 *>(rec + 16);
-      float4 cc = *reinterpret_cast<const float4 *>(rec + 32);
+      float4 na = *reinterpret_cast<const float4 *>(rec);
+      float4 nb = *reinterpret_cast<const float4 *>(rec + 16);
+      float4 nc = *reinterpret_cast<const float4 *>(rec + 32);
       int2 ch = *reinterpret_cast<const int2 *>(rec + 48);
       if (COUNT) nv++;
-      float left = slab_fast<PAR>(c, a.x, a.y, a.z, a.w, b.x, b.y);
-      float right = slab_fast<PAR>(c, b.z, b.w, cc.x, cc.y, cc.z, cc.w);
+      float left, right;
+      if (VARIANT == 2) {
+         left = slab_literal(c.r, na.x, na.y, na.z, na.w, nb.x, nb.y);
+         right = slab_literal(c.r, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w);
+      } else {
+         left = slab_fast<VARIANT == 1>(c, na.x, na.y, na.z, na.w, nb.x, nb.y);
+         right = slab_fast<VARIANT == 1>(c, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w);
+      }
       /* kernel.cu:148-158 as predicates: right first on `<=`, the other child deferred if it is ahead too */
       bool aL = above_zero(left), aR = above_zero(right);
       bool goR = aR && (right <= left || !aL) && right < t;
@@ -380,6 +472,60 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
       if (goR || goL) cur = goR ? ch.y : ch.x;
       else pop();
    };
+   /* OUT_CHAIN: every lane that finished since the last call writes its spawn record and appends its bounce rays */
+   auto spawn_stage = [&]() {
+      bool want_refl = false, want_refr = false, shaded = false;
+      BounceRays b;
+      SpawnRec out;
+      out.refl = out.alpha = 0.0f; out.child_refl = out.child_refr = -1;
+      if (pend && closest >= 0) {
+         shaded = true;
+         unsigned mat_id = closest < sc.n_prims ? sc.prims[closest].material : sc.planes[closest - sc.n_prims].material;
+         const rt_material &m = sc.materials[mat_id];
+         float m_refl = m.refl, m_refr = m.refr, m_ior = m.ior;
+         out.refl = m_refl; out.alpha = m.alpha;
+         if (tag < a.max_rec && (m_refl > 0.0f || m_refr > 0.0f)) {          /* tag = level + 1 */
+            b = bounce_rays(sc.prims, sc.xforms, sc.shades, sc.planes, sc.n_prims, c.r.o.x, c.r.o.y, c.r.o.z,
+                            c.r.d.x, c.r.d.y, c.r.d.z, closest, t, m_refl, m_refr, m_ior);
+            want_refl = b.want_refl != 0; want_refr = b.want_refr != 0;
+         }
+      }
+      stat_count(stats, ST_SHADE_NODES, shaded);
+      unsigned long long mR = __ballot(want_refl), mT = __ballot(want_refr);
+      unsigned cR = __popcll(mR), cT = __popcll(mT);
+      if (cR + cT) {
+         unsigned leader = (unsigned)__ffsll((long long)(mR | mT)) - 1;
+         unsigned base = 0;
+         if (lane == leader) base = atomicAdd(a.tail, cR + cT);
+         base = __shfl(base, leader);
+         unsigned slotR = base + __popcll(mR & below), slotT = base + cR + __popcll(mT & below);
+         bool okR = want_refl && slotR < a.cap, okT = want_refr && slotT < a.cap;
+         unsigned long long oR = __ballot(okR), oT = __ballot(okT);
+         unsigned nOk = __popcll(oR) + __popcll(oT);
+         bool room = lifo_count + (int)nOk <= RT_LIFO_CAP;
+         if (okR) {
+            store_qray(a.rays, slotR, mk3(b.ro[0], b.ro[1], b.ro[2]), mk3(b.rd[0], b.rd[1], b.rd[2]), -FLT_MAX, tag + 1);
+            out.child_refl = (int)slotR;
+            if (room) lifo[lifo_count + __popcll(oR & below)] = slotR;
+         }
+         if (okT) {
+            store_qray(a.rays, slotT, mk3(b.to[0], b.to[1], b.to[2]), mk3(b.td[0], b.td[1], b.td[2]), -FLT_MAX, tag + 1);
+            out.child_refr = (int)slotT;
+            if (room) lifo[lifo_count + __popcll(oR) + __popcll(oT & below)] = slotT;
+         }
+         if (room) lifo_count += (int)nOk;
+         if (lane == leader) {
+            stat_add(stats, ST_REFLECT, (unsigned long long)__popcll(oR));
+            stat_add(stats, ST_REFRACT, (unsigned long long)__popcll(oT));
+            if (nOk != cR + cT) stat_add(stats, ST_OVERFLOW, 1ULL);      /* the queue is full: the host retries with a larger one */
+            if (!room) stat_add(stats, ST_ABORTED, 1ULL);
+         }
+      }
+      if (pend) *reinterpret_cast<float4 *>(a.recs + idx) = make_float4(out.refl, out.alpha, __int_as_float(out.child_refl), __int_as_float(out.child_refr));
+      pend = false;
+      /* the rays just stored are read back by this wave only; make the stores complete before that */
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+   };
 
    /* Every wave reaches its exit in a bounded number of steps: a ray visits each node at most once per
     * stack entry, so RT_STEP_CAP is far beyond any real traversal; hitting it means a corrupted scene and
@@ -389,36 +535,46 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
       if (++guard > RT_STEP_CAP) { if (lane == 0) stat_add(stats, ST_ABORTED, 1ULL); break; }
       unsigned long long m_active = __ballot(active);
       int n_idle = 64 - __popcll(m_active);
-      if (!exhausted && n_idle >= RT_REFILL_IDLE) {
+      bool any_pend = OUT == OUT_CHAIN && __ballot(pend) != 0;
+      if ((n_idle >= RT_REFILL_IDLE || m_active == 0) && (!exhausted || lifo_count > 0 || any_pend)) {
+         if (any_pend) spawn_stage();
          unsigned long long m_idle = ~m_active;
-         int leader = __ffsll((long long)m_idle) - 1;
+         int rank = __popcll(m_idle & below);
+         int take = 0;
+         if (OUT == OUT_CHAIN) take = n_idle < lifo_count ? n_idle : lifo_count;
+         int need = exhausted ? 0 : n_idle - take;
          unsigned long long base = 0;
-         if ((int)lane == leader) base = atomicAdd(next, (unsigned long long)n_idle);
-         base = __shfl(base, leader);
-         if (base + (unsigned long long)n_idle >= n) exhausted = true;
+         if (need > 0) {
+            int leader = __ffsll((long long)m_idle) - 1;
+            if ((int)lane == leader) base = atomicAdd(a.next, (unsigned long long)need);
+            base = __shfl(base, leader);
+            if (base + (unsigned long long)need >= n) exhausted = true;
+         }
          if (!active) {
-            unsigned long long my = base + (unsigned long long)__popcll(m_idle & below);
-            if (my < n) {
-               QRay q = load_qray_rec(rays, my);
+            bool have = false, own = false;
+            unsigned long long my = 0;
+            if (rank < take) { my = lifo[lifo_count - 1 - rank]; have = true; own = true; }
+            else if (need > 0) { my = base + (unsigned long long)(rank - take); have = my < n; }
+            if (have) {
+               QRay q = own ? load_qray_written(a.rays, my) : load_qray_rec(a.rays, my);
                if (q.valid) {
                   Ray r; r.o = mk3(q.ox, q.oy, q.oz); r.d = mk3(q.dx, q.dy, q.dz);
                   c = make_ctx(r);
-                  if (c.fast && sc.fast_ok) {
-                     toBeat = q.to_beat; idx = (unsigned)my;
-                     t = FLT_MAX; closest = -1; sp = 0; cur = sc.root;
-                     active = true; ray_steps = 0;
-                     if (cur == RT_ROOT_EMPTY) finish(false);
-                  } else {
-                     slow_list[atomicAdd(slow_count, 1u)] = (unsigned)my;
-                  }
+                  if (!sc.fast_ok) c.fast = false;
+                  toBeat = q.to_beat; idx = (unsigned)my; tag = q.valid;
+                  t = FLT_MAX; closest = -1; sp = 0; cur = sc.root;
+                  active = true; ray_steps = 0;
+                  if (cur == RT_ROOT_EMPTY) finish(false);
                }
             }
          }
+         lifo_count -= take;
          m_active = __ballot(active);
          wave_par = __ballot(active && c.par != 0) != 0;
+         wave_lit = __ballot(active && !c.fast) != 0;
       }
       if (m_active == 0) {
-         if (exhausted) break;
+         if (exhausted && lifo_count == 0 && !(OUT == OUT_CHAIN && __ballot(pend) != 0)) break;
          continue;
       }
       /* ---- node steps ---- */
@@ -428,8 +584,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
          if (__ballot(in_node) == 0) break;
          if (COUNT) { wn++; if (active) ray_steps++; }
          if (in_node) {
-            if (wave_par) node_step(std::true_type());
-            else node_step(std::false_type());
+            if (wave_lit) node_step(std::integral_constant<int, 2>());
+            else if (wave_par) node_step(std::integral_constant<int, 1>());
+            else node_step(std::integral_constant<int, 0>());
          }
       }
       /* ---- leaf step ---- */
@@ -444,78 +601,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, const QRay *rays,
       }
    }
    if (COUNT) {
-      stat_add(stats, stat_base + 0, (unsigned long long)nv);
-      stat_add(stats, stat_base + 1, (unsigned long long)np);
-      stat_add(stats, stat_base + 2, (unsigned long long)nt);
+      stat_add(stats, a.stat_base + 0, (unsigned long long)nv);
+      stat_add(stats, a.stat_base + 1, (unsigned long long)np);
+      stat_add(stats, a.stat_base + 2, (unsigned long long)nt);
       if (lane == 0) {
-         stat_add(stats, stat_base + 3, (unsigned long long)wn);
-         stat_add(stats, stat_base + 4, (unsigned long long)wl);
+         stat_add(stats, a.stat_base + 3, (unsigned long long)wn);
+         stat_add(stats, a.stat_base + 4, (unsigned long long)wl);
       }
-      atomicMax(&stats[(stat_base == ST_NODE_VISITS ? ST_MAX_RAY_STEPS : ST_MAX_RAY_STEPS_SHADOW) * RT_STAT_REPL],
+      atomicMax(&stats[(a.stat_base == ST_NODE_VISITS ? ST_MAX_RAY_STEPS : ST_MAX_RAY_STEPS_SHADOW) * RT_STAT_REPL],
                 (unsigned long long)max_ray_steps);
-   }
-}
-
-/* k_trace_slow: the same query with the reference's literal box test (true divisions, parallel-axis
- * branches), one ray per thread, for the rays k_trace set aside.  Grid-stride over the device-side count. */
-template <int OUT, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_slow(DScene sc, const QRay *rays, Hit *hits, unsigned char *flags,
-                                                         const unsigned *slow_list, const unsigned *slow_count,
-                                                         unsigned long long *stats, int stat_base)
-{
-   StackEntry *stack = lds_stack + threadIdx.x;
-   const int stride = RT_BLOCK;
-   unsigned total = *slow_count;
-   unsigned nv = 0, np = 0, nt = 0;
-   for (unsigned k = blockIdx.x * RT_BLOCK + threadIdx.x; k < total; k += gridDim.x * RT_BLOCK) {
-      unsigned idx = slow_list[k];
-      QRay q = load_qray_rec(rays, idx);
-      Ray ray; ray.o = mk3(q.ox, q.oy, q.oz); ray.d = mk3(q.dx, q.dy, q.dz);
-      float toBeat = q.to_beat, t = FLT_MAX;
-      int closest = -1, cur = sc.root, sp = 0;
-      bool done = (cur == RT_ROOT_EMPTY), early = false;
-      unsigned long long guard = 0;
-      while (!done) {
-         if (++guard > RT_STEP_CAP) { stat_add(stats, ST_ABORTED, 1ULL); break; }
-         bool need_pop = false;
-         if (cur >= 0) {
-            float4 a, b, cc, d;
-            load_node(sc.nodes, cur, a, b, cc, d);
-            if (COUNT) nv++;
-            float left = slab_literal(ray, a.x, a.y, a.z, a.w, b.x, b.y);
-            float right = slab_literal(ray, b.z, b.w, cc.x, cc.y, cc.z, cc.w);
-            int li = __float_as_int(d.x), ri = __float_as_int(d.y);
-            bool aL = above_zero(left), aR = above_zero(right);
-            if (aR && (right <= left || !aL) && right < t) {
-               if (aL) { StackEntry e; e.child = li; e.dist = left; stack[sp * stride] = e; sp++; }
-               cur = ri;
-            } else if (aL && (left <= right || !aR) && left < t) {
-               if (aR) { StackEntry e; e.child = ri; e.dist = right; stack[sp * stride] = e; sp++; }
-               cur = li;
-            } else need_pop = true;
-         } else {
-            if (COUNT) np++;
-            if (leaf_test(sc, ray, ~cur, toBeat, t, closest, nt)) { early = true; done = true; }
-            else need_pop = true;
-         }
-         if (need_pop) {
-            bool found = false;
-            while (sp > 0) {
-               sp--;
-               StackEntry e = stack[sp * stride];
-               if (e.dist < t) { cur = e.child; found = true; break; }
-            }
-            if (!found) done = true;
-         }
-      }
-      if (!early) plane_scan(sc, ray, t, closest);
-      if (OUT == OUT_HIT) { Hit h; h.prim = closest; h.t = t; hits[idx] = h; }
-      else flags[idx] = less_than(t, toBeat) ? 1 : 0;
-   }
-   if (COUNT) {
-      stat_add(stats, stat_base + 0, (unsigned long long)nv);
-      stat_add(stats, stat_base + 1, (unsigned long long)np);
-      stat_add(stats, stat_base + 2, (unsigned long long)nt);
    }
 }
 
@@ -569,35 +663,43 @@ __device__ __forceinline__ Ray camera_ray(const DCamera &cam, const DGrid &g, in
 /* kernels                                                                  */
 /* ======================================================================= */
 
-/* generate: the primary ray of every sample slot of the batch (slots outside the frame are invalid) */
-__global__ __launch_bounds__(RT_BLOCK) void k_generate(DCamera cam, DGrid g, long long n, QRay *queue, Hit *hits,
-                                                       unsigned long long *stats)
+/* generate: the primary ray of every sample slot of the batch (slots outside the frame are invalid and get
+ * the result of a miss right away) */
+__global__ __launch_bounds__(RT_BLOCK) void k_generate(DCamera cam, DGrid g, long long n, QRay *queue, Hit *hits, SpawnRec *recs,
+                                                       unsigned *tail, unsigned long long *stats)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
    int X = 0, Y = 0;
    bool valid = i < n && slot_to_sample(g, i, X, Y);
+   if (i == 0 && tail) *tail = (unsigned)n;       /* spawned rays are appended behind the primaries */
    if (i < n) {
       Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
       if (valid) r = camera_ray(cam, g, X, Y);
       store_qray(queue, (unsigned long long)i, r.o, r.d, -FLT_MAX, valid ? 1 : 0);
-      if (!valid) { Hit h; h.prim = -1; h.t = FLT_MAX; hits[i] = h; }
+      if (!valid) {
+         Hit h; h.prim = -1; h.t = FLT_MAX; hits[i] = h;
+         if (recs) *reinterpret_cast<float4 *>(recs + i) = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));
+      }
    }
    stat_count(stats, ST_PRIMARY, valid);
 }
 
-/* shadow set-up: the feeler of (light = blockIdx.y, node = x) into the shadow queue at light*n + node */
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow_setup(DScene sc, const QRay *queue, const Hit *hits, long long n,
-                                                           QRay *shadow_queue, unsigned char *flags,
-                                                           unsigned long long *stats)
+/* shadow set-up: the feeler of (light = blockIdx.y, node = x).  Feelers that have to be traced are appended
+ * to a compact queue (one atomic per wave); valid - 1 is the feeler's slot in the flag array, light*cap + node.
+ * The number of nodes comes from the device (the chain kernel's tail). */
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow_setup(DScene sc, const QRay *queue, const Hit *hits, const unsigned *n_dev,
+                                                           unsigned cap, QRay *shadow_queue, unsigned *shadow_count,
+                                                           unsigned char *flags, unsigned long long *stats)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+   unsigned n = *n_dev < cap ? *n_dev : cap;
    int light = blockIdx.y;
    bool valid = false, skipped = false;
-   if (i < n) {
-      unsigned long long out = (unsigned long long)light * (unsigned long long)n + (unsigned long long)i;
+   F3 lp = mk3(0, 0, 0), fd = mk3(0, 0, 1);
+   float param = -1.0f;
+   unsigned long long out = (unsigned long long)light * (unsigned long long)cap + (unsigned long long)i;
+   if (i < (long long)n) {
       Hit h = hits[i];
-      F3 lp = mk3(0, 0, 0), fd = mk3(0, 0, 1);
-      float param = -1.0f;
       if (h.prim >= 0) {
          Ray ray = load_qray(queue, i);
          F3 P = ray_point(ray, h.t);                                   /* kernel.cu:340 */
@@ -612,8 +714,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_setup(DScene sc, const QRay
          valid = param != -1.0f;
          skipped = !valid;
       }
-      store_qray(shadow_queue, out, lp, fd, param, valid ? 1 : 0);
       if (!valid) flags[out] = 0;
+   }
+   unsigned long long m = __ballot(valid);
+   if (m) {
+      unsigned lane = __lane_id();
+      unsigned leader = (unsigned)__ffsll((long long)m) - 1;
+      unsigned base = 0;
+      if (lane == leader) base = atomicAdd(shadow_count, (unsigned)__popcll(m));
+      base = __shfl(base, leader);
+      unsigned long long below = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+      if (valid) store_qray(shadow_queue, base + __popcll(m & below), lp, fd, param, (int)out + 1);
    }
    stat_count(stats, ST_SHADOW_TRACED, valid);
    stat_count(stats, ST_SHADOW_SKIPPED, skipped);
@@ -672,86 +783,20 @@ __device__ __forceinline__ ShadePoint shade_point(const DScene &sc, const QRay *
    return sp;
 }
 
-/* spawn: the reflection / refraction rays of every hit of a level (getReflection / getRefraction,
- * kernel.cu:209-276, guarded as in kernel.cu:361-371) into the next level's queue.  It needs no shadow
- * result, so it runs right behind the level's extend while the shadow rays are traced elsewhere. */
-__global__ __launch_bounds__(RT_BLOCK) void k_spawn(DScene sc, const QRay *queue, const Hit *hits, long long n, int spawn,
-                                                    SpawnRec *recs, QRay *next_queue, unsigned *next_count,
-                                                    unsigned next_cap, unsigned long long *stats)
-{
-   long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-   bool want_refl = false, want_refr = false, shaded = false;
-   Ray reflRay, refrRay;
-   reflRay.o = reflRay.d = refrRay.o = refrRay.d = mk3(0, 0, 0);
-   SpawnRec out;
-   out.refl = out.alpha = 0.0f; out.child_refl = out.child_refr = -1;
-   if (i < n) {
-      Hit h = hits[i];
-      if (h.prim >= 0) {
-         shaded = true;
-         unsigned mat_id = h.prim < sc.n_prims ? sc.prims[h.prim].material : sc.planes[h.prim - sc.n_prims].material;
-         const rt_material &m = sc.materials[mat_id];
-         out.refl = m.refl; out.alpha = m.alpha;
-         if (spawn && (m.refl > 0.0f || m.refr > 0.0f)) {
-            ShadePoint sp = shade_point(sc, queue, i, h);
-            if (sp.m.refl > 0.0f) {
-               /* getReflection, kernel.cu:214-216 */
-               reflRay.d = (2.0f * dot3(sp.normal, sp.eye)) * sp.normal - sp.eye;
-               reflRay.o = sp.P + RT_BIG_EPS * reflRay.d;
-               want_refl = true;
-            }
-            if (sp.m.refr > 0.0f) {
-               /* getRefraction, kernel.cu:239-257 */
-               float n1, n2; F3 refrNorm; F3 dd = -sp.eye;
-               if (less_than(dot3(sp.eye, sp.normal), 0.0f)) { n1 = sp.m.ior; n2 = RT_AIR_IOR; refrNorm = -sp.normal; }
-               else { n1 = RT_AIR_IOR; n2 = sp.m.ior; refrNorm = sp.normal; }
-               float dDotN = dot3(dd, refrNorm);
-               float nr = n1 / n2;
-               float disc = 1.0f - nr * nr * (1.0f - dDotN * dDotN);
-               if (disc > 0.0f) {
-                  refrRay.d = nr * (dd - refrNorm * dDotN) - refrNorm * sqrtf(disc);
-                  refrRay.o = sp.P + RT_BIG_EPS * refrRay.d;
-                  want_refr = true;
-               }
-            }
-         }
-      }
-   }
-   stat_count(stats, ST_SHADE_NODES, shaded);
-   if (spawn) {
-      /* wave-aggregated queue allocation: the wave's reflection rays land contiguously, then its refraction rays */
-      unsigned long long mR = __ballot(want_refl), mT = __ballot(want_refr);
-      unsigned cR = __popcll(mR), cT = __popcll(mT);
-      if (cR + cT) {
-         unsigned lane = __lane_id();
-         unsigned leader = (unsigned)__ffsll((long long)(mR | mT)) - 1;
-         unsigned base = 0;
-         if (lane == leader) base = atomicAdd(next_count, cR + cT);
-         base = __shfl(base, leader);
-         unsigned long long below = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
-         if (want_refl) {
-            unsigned slot = base + __popcll(mR & below);
-            if (slot < next_cap) { store_qray(next_queue, slot, reflRay.o, reflRay.d, -FLT_MAX, 1); out.child_refl = (int)slot; }
-         }
-         if (want_refr) {
-            unsigned slot = base + cR + __popcll(mT & below);
-            if (slot < next_cap) { store_qray(next_queue, slot, refrRay.o, refrRay.d, -FLT_MAX, 1); out.child_refr = (int)slot; }
-         }
-         if (lane == leader) {
-            stat_add(stats, ST_REFLECT, (unsigned long long)cR);
-            stat_add(stats, ST_REFRACT, (unsigned long long)cT);
-         }
-      }
-   }
-   if (i < n) *reinterpret_cast<float4 *>(recs + i) = make_float4(out.refl, out.alpha, __int_as_float(out.child_refl), __int_as_float(out.child_refr));
-}
-
-/* light: totalLight of every hit of a level, the loop of kernel.cu:347-358 with the shadow flags of the level */
+/* light: totalLight of every node, the loop of kernel.cu:347-358 with the shadow flags.  Thread 0 also notes
+ * how many queue entries the chain kernel wanted per primary (in sixteenths) so the host can size the next frame. */
 __global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue, const Hit *hits, const unsigned char *flags,
-                                                    long long n, int shading, float *totals)
+                                                    const unsigned *n_dev, unsigned cap, unsigned n_primary, int shading,
+                                                    float *totals, unsigned long long *stats)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-   if (i >= n) return;
+   unsigned wanted = *n_dev;
+   unsigned n = wanted < cap ? wanted : cap;
+   if (i == 0 && n_primary > 0) {
+      unsigned long long ratio = ((unsigned long long)wanted * 16ULL + n_primary - 1) / n_primary;
+      atomicMax(&stats[ST_NODES_PER_PRIMARY_X16 * RT_STAT_REPL], ratio);
+   }
+   if (i >= (long long)n) return;
    Hit h = hits[i];
    F3 total = mk3(0.0f, 0.0f, 0.0f);
    if (h.prim >= 0) {
@@ -761,7 +806,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue
          const rt_dev_light &L = sc.lights[l];
          F3 lc = mk3(L.clr[0], L.clr[1], L.clr[2]);
          F3 lightDir = normalize3(mk3(L.pos[0], L.pos[1], L.pos[2]) - sp.P);    /* PointLight.h:14-16 */
-         bool inShadow = flags[(long long)l * n + i] != 0;
+         bool inShadow = flags[(long long)l * cap + i] != 0;
          F3 c = shading == RT_COOK_TORRANCE
                    ? cook_torrance(matClr, sp.m.amb, sp.m.dif, sp.m.spec, sp.m.rough, sp.eye, lightDir, lc, sp.normal, inShadow)
                    : phong(matClr, sp.m.amb, sp.m.dif, sp.m.spec, sp.m.rough, sp.eye, lightDir, lc, sp.normal, inShadow);
@@ -771,26 +816,42 @@ __global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue
    totals[3 * i] = total.x; totals[3 * i + 1] = total.y; totals[3 * i + 2] = total.z;
 }
 
-/* combine: colour of node i of a level from its own light sum and its children's colours
- * (kernel.cu:375-376).  child colours of a missing ray are the reference's vec3(0). */
-__global__ __launch_bounds__(RT_BLOCK) void k_combine(const SpawnRec *recs, const float *totals, const float *child_rgb,
-                                                      long long n, float *rgb, int clamp_out)
+/* combine: the colour of primary i from the light sums of its bounce tree, children before parents:
+ *   colour(node) = total*(1 - refl - alpha) + refl*colour(reflected) + alpha*colour(refracted)      (kernel.cu:375-376)
+ * with vec3(0) for a ray that was not spawned or hit nothing.  One thread walks one tree (at most
+ * 2^RT_MAX_RECURSE - 1 nodes, usually a short chain) with an explicit stack of one frame per level, so every
+ * node is evaluated once, by one thread, in the reference's operand order: no atomics, no races. */
+__global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs, const float *totals, long long n_primary, float *rgb)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-   if (i >= n) return;
-   float4 rr = *reinterpret_cast<const float4 *>(recs + i);
-   float w_refl = rr.x, w_alpha = rr.y;
-   int child_refl = __float_as_int(rr.z), child_refr = __float_as_int(rr.w);
-   F3 refl = mk3(0.0f, 0.0f, 0.0f), refr = mk3(0.0f, 0.0f, 0.0f);
-   if (child_refl >= 0) refl = mk3(child_rgb[3LL * child_refl], child_rgb[3LL * child_refl + 1], child_rgb[3LL * child_refl + 2]);
-   if (child_refr >= 0) refr = mk3(child_rgb[3LL * child_refr], child_rgb[3LL * child_refr + 1], child_rgb[3LL * child_refr + 2]);
-   F3 total = mk3(totals[3 * i], totals[3 * i + 1], totals[3 * i + 2]);
-   F3 c = total * (1.0f - w_refl - w_alpha) + w_refl * refl + w_alpha * refr;
-   if (clamp_out) {
-      /* rayTrace's clamp (kernel.cu:537-539); NaN passes through clamp unchanged (Util.h:28-30) */
-      c = mk3(clamp01(c.x), clamp01(c.y), clamp01(c.z));
+   if (i >= n_primary) return;
+   int node[RT_MAX_RECURSE], stage[RT_MAX_RECURSE];
+   float rx[RT_MAX_RECURSE], ry[RT_MAX_RECURSE], rz[RT_MAX_RECURSE];
+   int sp = 0;
+   node[0] = (int)i; stage[0] = 0;
+   F3 ret = mk3(0.0f, 0.0f, 0.0f);
+   while (sp >= 0) {
+      float4 rr = *reinterpret_cast<const float4 *>(recs + node[sp]);
+      int child_refl = __float_as_int(rr.z), child_refr = __float_as_int(rr.w);
+      if (stage[sp] == 0) {
+         stage[sp] = 1;
+         if (child_refl >= 0 && sp + 1 < RT_MAX_RECURSE) { sp++; node[sp] = child_refl; stage[sp] = 0; continue; }
+         ret = mk3(0.0f, 0.0f, 0.0f);
+      }
+      if (stage[sp] == 1) {
+         rx[sp] = ret.x; ry[sp] = ret.y; rz[sp] = ret.z;
+         stage[sp] = 2;
+         if (child_refr >= 0 && sp + 1 < RT_MAX_RECURSE) { sp++; node[sp] = child_refr; stage[sp] = 0; continue; }
+         ret = mk3(0.0f, 0.0f, 0.0f);
+      }
+      long long k = node[sp];
+      F3 total = mk3(totals[3 * k], totals[3 * k + 1], totals[3 * k + 2]);
+      F3 refl = mk3(rx[sp], ry[sp], rz[sp]);
+      ret = total * (1.0f - rr.x - rr.y) + rr.x * refl + rr.y * ret;
+      sp--;
    }
-   rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
+   /* rayTrace's clamp (kernel.cu:537-539); NaN passes through clamp unchanged (Util.h:28-30) */
+   rgb[3 * i] = clamp01(ret.x); rgb[3 * i + 1] = clamp01(ret.y); rgb[3 * i + 2] = clamp01(ret.z);
 }
 
 __device__ __forceinline__ unsigned char to_byte(float v)
@@ -892,16 +953,15 @@ struct rt_scene {
    size_t dev_bytes;
    float ms_build_host, ms_upload;
    Arena arena;             /* per-frame queues; grown on demand, reused across frames */
-   unsigned *d_counts;      /* queue counters, one per depth level */
-   unsigned long long *d_next;   /* work counters of the persistent traversal launches (one per launch of a batch) */
+   unsigned long long *d_ctr;    /* work counters of the chunks in flight: RT_RING x 8 words (see ChunkCtr) */
    unsigned long long *d_stats;
-   unsigned *h_counts;      /* pinned */
-   unsigned long long *h_stats;
-   /* Two internal streams: the bounce chain (extend -> spawn -> extend ...) is a sequence of launches each
-    * bounded below by its longest ray, so it runs on `chain` while the shadow rays and
-    * light sums of the levels already extended fill the machine from `side`. */
+   unsigned long long *h_stats;  /* pinned */
+   float node_factor;       /* queue entries per primary ray the chain kernel gets room for; grows when a frame overflows */
+   /* Two internal streams: `chain` traces the bounce trees of one chunk of tiles after the other, `side` runs
+    * the shadow rays, light sums, combine and resolve of the chunks the chain is through with, so that the
+    * tail of each traversal launch (its longest rays) overlaps the bulk of the other stream's. */
    hipStream_t chain, side;
-   hipEvent_t ev_level[RT_MAX_RECURSE], ev_begin, ev_side_done, ev_end;
+   hipEvent_t ev_chain[RT_RING], ev_side[RT_RING], ev_begin, ev_end;
    bool streams_ok;
 };
 
@@ -926,15 +986,13 @@ extern "C" void rt_scene_destroy(rt_scene *s)
    if (s->device >= 0) (void)hipSetDevice(s->device);
    if (s->dev_blob) (void)hipFree(s->dev_blob);
    if (s->arena.base) (void)hipFree(s->arena.base);
-   if (s->d_counts) (void)hipFree(s->d_counts);
-   if (s->d_next) (void)hipFree(s->d_next);
+   if (s->d_ctr) (void)hipFree(s->d_ctr);
    if (s->d_stats) (void)hipFree(s->d_stats);
-   if (s->h_counts) (void)hipHostFree(s->h_counts);
    if (s->h_stats) (void)hipHostFree(s->h_stats);
    if (s->streams_ok) {
       (void)hipStreamDestroy(s->chain); (void)hipStreamDestroy(s->side);
-      for (int l = 0; l < RT_MAX_RECURSE; l++) (void)hipEventDestroy(s->ev_level[l]);
-      (void)hipEventDestroy(s->ev_begin); (void)hipEventDestroy(s->ev_side_done); (void)hipEventDestroy(s->ev_end);
+      for (int l = 0; l < RT_RING; l++) { (void)hipEventDestroy(s->ev_chain[l]); (void)hipEventDestroy(s->ev_side[l]); }
+      (void)hipEventDestroy(s->ev_begin); (void)hipEventDestroy(s->ev_end);
    }
    rt_flat_scene_free(&s->host);
    delete s;
@@ -949,7 +1007,7 @@ extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
    memset(&s->host, 0, sizeof s->host);
    memset(&s->d, 0, sizeof s->d);
    s->device = -1; s->flags = 0; s->streams_ok = false;
-   s->dev_blob = nullptr; s->dev_bytes = 0; s->d_counts = nullptr; s->d_next = nullptr; s->d_stats = nullptr; s->h_counts = nullptr; s->h_stats = nullptr;
+   s->dev_blob = nullptr; s->dev_bytes = 0; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
    s->camera = desc->camera; s->has_camera = desc->has_camera; s->ms_upload = 0;
    auto t0 = std::chrono::steady_clock::now();
    int st = rt_flatten_scene(desc, &s->host);
@@ -972,7 +1030,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    if (!s) return RT_ERR_BAD_ARGUMENT;
    memset(&s->host, 0, sizeof s->host);
    s->device = device; s->flags = flags; s->streams_ok = false;
-   s->dev_blob = nullptr; s->d_counts = nullptr; s->d_next = nullptr; s->d_stats = nullptr; s->h_counts = nullptr; s->h_stats = nullptr;
+   s->dev_blob = nullptr; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
    s->camera = desc->camera; s->has_camera = desc->has_camera;
 
    auto t0 = std::chrono::steady_clock::now();
@@ -1006,19 +1064,18 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->d.n_prims = h.n_prims; s->d.n_planes = h.n_planes; s->d.n_lights = h.n_lights; s->d.root = h.root;
    s->d.fast_ok = h.bounds_in_range;
 
-   if (hipMalloc((void **)&s->d_counts, 64 * sizeof(unsigned)) != hipSuccess ||
-       hipMalloc((void **)&s->d_next, 64 * sizeof(unsigned long long)) != hipSuccess ||
+   if (hipMalloc((void **)&s->d_ctr, RT_RING * 8 * sizeof(unsigned long long)) != hipSuccess ||
        hipMalloc((void **)&s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long)) != hipSuccess ||
-       hipHostMalloc((void **)&s->h_counts, 64 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
        hipHostMalloc((void **)&s->h_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
       rt_set_error("allocation of queue counters failed"); rt_scene_destroy(s); return RT_ERR_HIP;
    }
    {
       bool ok = hipStreamCreateWithFlags(&s->chain, hipStreamNonBlocking) == hipSuccess;
       ok = ok && hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) == hipSuccess;
-      for (int l = 0; l < RT_MAX_RECURSE && ok; l++) ok = hipEventCreateWithFlags(&s->ev_level[l], hipEventDisableTiming) == hipSuccess;
+      for (int l = 0; l < RT_RING && ok; l++)
+         ok = hipEventCreateWithFlags(&s->ev_chain[l], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_side[l], hipEventDisableTiming) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&s->ev_begin, hipEventDisableTiming) == hipSuccess;
-      ok = ok && hipEventCreateWithFlags(&s->ev_side_done, hipEventDisableTiming) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&s->ev_end, hipEventDisableTiming) == hipSuccess;
       if (!ok) { rt_set_error("stream / event creation failed"); rt_scene_destroy(s); return RT_ERR_HIP; }
       s->streams_ok = true;
@@ -1092,18 +1149,6 @@ static int arena_reserve(Arena &a, size_t bytes)
    return RT_OK;
 }
 
-/* offsets into the arena (the arena may be re-allocated between levels) */
-struct LevelBufs {
-   long long n = 0;
-   size_t queue = 0;      /* QRay[n], level >= 1 */
-   size_t hits = 0;       /* Hit[n] */
-   size_t recs = 0;       /* SpawnRec[n] */
-   size_t totals = 0;     /* float[3n]: light sums */
-   size_t rgb = 0;        /* float[3n] */
-   size_t slow = 0;       /* unsigned[n]: rays set aside for the literal-arithmetic kernel */
-   bool has_queue = false;
-};
-
 struct Timer {
    hipEvent_t a, b;
    bool ok = false, ended = false;
@@ -1147,18 +1192,17 @@ static long long max_batch_slots()
 
 static int trace_lds_bytes(const rt_scene *s, size_t *out)
 {
-   /* the stack holds at most one deferred sibling per internal level */
-   size_t lds_bytes = sizeof(StackEntry) * (size_t)RT_BLOCK * (size_t)(s->host.tree_depth > 0 ? s->host.tree_depth : 1);
+   /* the stack holds at most one deferred sibling per internal level; behind it, one list of spawned rays per wave */
+   int depth = s->host.tree_depth > 0 ? s->host.tree_depth : 1;
+   size_t lds_bytes = sizeof(StackEntry) * (size_t)RT_BLOCK * (size_t)depth + (RT_BLOCK / 64) * RT_LIFO_CAP * sizeof(unsigned);
    if (lds_bytes > 160 * 1024) { rt_set_error("BVH depth %d needs %zu bytes of LDS", s->host.tree_depth, lds_bytes); return RT_ERR_TOO_LARGE; }
    if (lds_bytes > 64 * 1024) {
       HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_HIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_HIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_FLAG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_FLAG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_trace_slow<OUT_HIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_trace_slow<OUT_HIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_trace_slow<OUT_FLAG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_trace_slow<OUT_FLAG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_CHAIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_CHAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
    }
    *out = lds_bytes;
    return RT_OK;
@@ -1167,10 +1211,8 @@ static int trace_lds_bytes(const rt_scene *s, size_t *out)
 static int g_trace_blocks = 0;
 
 /* persistent traversal launch: enough blocks to fill the chip a few times over; every wave pulls rays until
- * the queue is dry.  `next` is this launch's zeroed work counter, next[1] (as unsigned) the slow-ray count;
- * slow_list has room for n indices. */
-static void launch_trace(const rt_scene *s, bool flag_out, bool count, const QRay *rays, unsigned long long n, Hit *hits,
-                         unsigned char *flags, unsigned long long *next, unsigned *slow_list, size_t lds_bytes,
+ * the queue is dry.  `n_hint` bounds the number of rays (it sizes the grid when the count lives on the device). */
+static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs a, unsigned long long n_hint, size_t lds_bytes,
                          hipStream_t stream)
 {
    if (g_trace_blocks == 0) {
@@ -1180,26 +1222,38 @@ static void launch_trace(const rt_scene *s, bool flag_out, bool count, const QRa
       if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
       g_trace_blocks = e && atoi(e) > 0 ? atoi(e) : cus * 8;
    }
-   unsigned long long want = (n + RT_BLOCK - 1) / RT_BLOCK;
+   unsigned long long want = (n_hint + RT_BLOCK - 1) / RT_BLOCK;
    unsigned blocks = (unsigned)(want < (unsigned long long)g_trace_blocks ? want : (unsigned long long)g_trace_blocks);
    if (blocks == 0) return;
-   unsigned slow_blocks = blocks < 128 ? blocks : 128;
-   int base = flag_out ? ST_NODE_VISITS_SHADOW : ST_NODE_VISITS;
-   unsigned *slow_count = reinterpret_cast<unsigned *>(next + 1);
-#define RT_LAUNCH_TRACE(O, C)                                                                                                      \
-   do {                                                                                                                            \
-      hipLaunchKernelGGL((k_trace<O, C>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, rays, n, hits, flags, next,       \
-                         slow_list, slow_count, s->d_stats, base);                                                                 \
-      hipLaunchKernelGGL((k_trace_slow<O, C>), dim3(slow_blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, rays, hits, flags,      \
-                         (const unsigned *)slow_list, (const unsigned *)slow_count, s->d_stats, base);                             \
-   } while (0)
-   if (flag_out) { if (count) RT_LAUNCH_TRACE(OUT_FLAG, true); else RT_LAUNCH_TRACE(OUT_FLAG, false); }
+   a.stat_base = out_mode == OUT_FLAG ? ST_NODE_VISITS_SHADOW : ST_NODE_VISITS;
+   a.stack_depth = s->host.tree_depth > 0 ? s->host.tree_depth : 1;
+   a.stats = s->d_stats;
+#define RT_LAUNCH_TRACE(O, C) hipLaunchKernelGGL((k_trace<O, C>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, a)
+   if (out_mode == OUT_FLAG) { if (count) RT_LAUNCH_TRACE(OUT_FLAG, true); else RT_LAUNCH_TRACE(OUT_FLAG, false); }
+   else if (out_mode == OUT_CHAIN) { if (count) RT_LAUNCH_TRACE(OUT_CHAIN, true); else RT_LAUNCH_TRACE(OUT_CHAIN, false); }
    else { if (count) RT_LAUNCH_TRACE(OUT_HIT, true); else RT_LAUNCH_TRACE(OUT_HIT, false); }
 #undef RT_LAUNCH_TRACE
 }
 
-/* The frame driver: body of launch_kernel after scene set-up (kernel.cu:735-760), over the
- * tiles this call selects, in batches of tiles that bound the queue memory. */
+/* device counters of one chunk in flight (8 words of rt_scene::d_ctr) */
+struct ChunkCtr {
+   unsigned long long *next_chain, *next_shadow;
+   unsigned *tail, *shadow_count;
+};
+static ChunkCtr chunk_ctr(const rt_scene *s, int ring)
+{
+   unsigned long long *b = s->d_ctr + 8 * ring;
+   ChunkCtr c;
+   c.next_chain = b; c.next_shadow = b + 1;
+   c.tail = reinterpret_cast<unsigned *>(b + 2); c.shadow_count = reinterpret_cast<unsigned *>(b + 3);
+   return c;
+}
+
+/* The frame driver: body of launch_kernel after scene set-up (kernel.cu:735-760), over the tiles this call
+ * selects.  The tiles are cut into chunks; a chunk is generate -> chain (its whole bounce forest in one
+ * persistent launch) on one stream, then shadow set-up -> shadow trace -> light -> combine -> resolve on the
+ * other.  Nothing is read back while the frame is in flight; the queue capacity per primary ray is a guess
+ * that the device checks, and a frame that overflowed it is rendered again with a larger one. */
 static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, void *out_dev, int *prim_dev,
                        float *t_dev, float *rgb_dev, hipStream_t stream, rt_stats *stats_out)
 {
@@ -1218,6 +1272,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    if (max_rec > RT_MAX_RECURSE) { rt_set_error("max_recurse > %d", RT_MAX_RECURSE); return RT_ERR_BAD_ARGUMENT; }
    if ((long long)p->width * sroot > 0x3fffffff / (long long)(p->height * (long long)sroot)) { rt_set_error("frame too large"); return RT_ERR_TOO_LARGE; }
    HIP_TRY(hipSetDevice(s->device));
+   if (view == VIEW_PRIMARY) max_rec = 1;
 
    int tile_first = p->tile_first, tile_stride = p->tile_stride > 0 ? p->tile_stride : 1;
    int n_sel = rt_tile_count(p->width, p->height, tile_first, tile_stride);
@@ -1235,188 +1290,144 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    const DScene &sc = s->d;
    const int L = sc.n_lights;
    const bool count = (s->flags & RT_SCENE_COUNTERS) != 0;
-
-   long long per_tile = (long long)g.ts * g.ts;
-   /* a batch is bounded by its sample slots and by its shadow rays (one 33-byte queue entry per light per node) */
-   long long batch_slots = max_batch_slots();
-   if (L > 0 && batch_slots * L > (1LL << 28)) batch_slots = (1LL << 28) / L;
-   long long tiles_per_batch = batch_slots / per_tile;
-   if (tiles_per_batch < 1) tiles_per_batch = 1;
+   const long long per_tile = (long long)g.ts * g.ts;
    size_t lds_bytes = 0;
    { int rc = trace_lds_bytes(s, &lds_bytes); if (rc != RT_OK) return rc; }
-
-   /* the caller's stream brackets the frame; the work itself runs on the two internal streams */
    hipStream_t M = s->chain, H = s->side;
    { const char *e = getenv("RT_SINGLE_STREAM"); if (e && atoi(e)) H = M; }
-   EventPool ev;
-   Timer &t_total = ev.begin(stream, &st.ms_total);
-   HIP_TRY(hipEventRecord(s->ev_begin, stream));
-   HIP_TRY(hipStreamWaitEvent(M, s->ev_begin, 0));
-   HIP_TRY(hipMemsetAsync(s->d_stats, 0, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), M));
 
-   for (long long k0 = 0; k0 < n_sel; k0 += tiles_per_batch) {
-      long long nb = n_sel - k0 < tiles_per_batch ? n_sel - k0 : tiles_per_batch;
-      g.k0 = (int)k0;
-      LevelBufs lv[RT_MAX_RECURSE];
-      lv[0].n = nb * per_tile;
+   for (int attempt = 0;; attempt++) {
+      memset(&st, 0, sizeof st);
+      /* chunk size: a chunk is bounded by its queue entries (2^24 primaries), by its shadow feelers (one
+       * 33-byte entry per light per queue entry, 2^28 of them) and wants to be a quarter of the frame or less
+       * so that the two streams have something to overlap, but not so small that launches dominate */
+      double F = max_rec > 1 ? (double)s->node_factor : 1.0;
+      long long slots_cap = max_batch_slots();
+      if (L > 0 && (double)slots_cap * F * L > (double)(1LL << 28)) slots_cap = (long long)((double)(1LL << 28) / (F * L));
+      long long tiles_cap = slots_cap / per_tile; if (tiles_cap < 1) tiles_cap = 1;
+      long long tiles_min = (128 * 1024) / per_tile; if (tiles_min < 1) tiles_min = 1;
+      long long chunk_tiles = n_sel;
+      { const char *e = getenv("RT_CHUNK_TILES"); if (e && atoll(e) > 0) chunk_tiles = atoll(e); else if (chunk_tiles < tiles_min) chunk_tiles = tiles_min; }
+      if (chunk_tiles > tiles_cap) chunk_tiles = tiles_cap;
+      if (chunk_tiles > n_sel) chunk_tiles = n_sel;
+      const long long n_chunks = (n_sel + chunk_tiles - 1) / chunk_tiles;
+      const int ring = (int)(n_chunks < RT_RING ? n_chunks : RT_RING);
 
-      /* Arena: a bump allocator re-used by every frame.  Level l+1's queue is carved for the worst case
-       * (two rays per node of level l) and trimmed to the real count once that is known; everything else
-       * of a batch stays allocated until the batch is done, because the side stream works behind the chain. */
+      /* one arena slice per chunk in flight, sized for the largest chunk */
+      const long long np_max = chunk_tiles * per_tile;
+      long long cap_ll = (long long)((double)np_max * F) + 64;
+      if (cap_ll > 0x7fffffffLL / (L > 0 ? L : 1)) { rt_set_error("ray queue too large"); return RT_ERR_TOO_LARGE; }
+      const unsigned cap = (unsigned)cap_ll;
       size_t used = 0;
       auto carve = [&](size_t bytes) { size_t o = used; used += align_up(bytes ? bytes : 1, 256); return o; };
-      auto grow = [&](size_t keep) -> int {
-         if (used <= s->arena.cap) return RT_OK;
-         HIP_TRY(hipDeviceSynchronize());
-         Arena bigger;
-         int rc = arena_reserve(bigger, used * 2);
-         if (rc != RT_OK) return rc;
-         if (keep && s->arena.base) HIP_TRY(hipMemcpy(bigger.base, s->arena.base, keep, hipMemcpyDeviceToDevice));
-         if (s->arena.base) HIP_TRY(hipFree(s->arena.base));
-         s->arena = bigger;
-         return RT_OK;
-      };
-      auto carve_level = [&](LevelBufs &b) {
-         b.hits = carve(sizeof(Hit) * (size_t)b.n);
-         b.recs = carve(sizeof(SpawnRec) * (size_t)b.n);
-         b.totals = carve(sizeof(float) * 3 * (size_t)b.n);
-         b.rgb = carve(sizeof(float) * 3 * (size_t)b.n);
-         b.slow = carve(sizeof(unsigned) * (size_t)b.n);
-      };
-      if (k0 > 0) HIP_TRY(hipDeviceSynchronize());   /* the previous batch still owns the arena */
-      lv[0].queue = carve(sizeof(QRay) * (size_t)lv[0].n); lv[0].has_queue = true;
-      carve_level(lv[0]);
-      { int rc = grow(0); if (rc != RT_OK) return rc; }
-#define AT(T, off) ((T *)(s->arena.base + (off)))
+      const size_t o_queue = carve(sizeof(QRay) * (size_t)cap), o_hits = carve(sizeof(Hit) * (size_t)cap);
+      const size_t o_recs = carve(sizeof(SpawnRec) * (size_t)cap), o_totals = carve(sizeof(float) * 3 * (size_t)cap);
+      const size_t o_rgb = carve(sizeof(float) * 3 * (size_t)np_max);
+      const size_t n_feelers = (size_t)(L > 0 ? L : 0) * (size_t)cap;
+      const size_t o_shq = carve(sizeof(QRay) * n_feelers), o_flags = carve(n_feelers);
+      const size_t slice = used;
+      if (slice * (size_t)ring > s->arena.cap) { int rc = arena_reserve(s->arena, slice * (size_t)ring); if (rc != RT_OK) return rc; }
+#define AT(T, r, off) ((T *)(s->arena.base + (size_t)(r) * slice + (off)))
 
-      HIP_TRY(hipMemsetAsync(s->d_counts, 0, 64 * sizeof(unsigned), M));
-      HIP_TRY(hipMemsetAsync(s->d_next, 0, 64 * sizeof(unsigned long long), M));
-      int n_trace = 0;   /* index of the next unused work counter */
+      /* the caller's stream brackets the frame; the work itself runs on the two internal streams */
+      EventPool ev;
+      Timer &t_total = ev.begin(stream, &st.ms_total);
+      HIP_TRY(hipEventRecord(s->ev_begin, stream));
+      HIP_TRY(hipStreamWaitEvent(M, s->ev_begin, 0));
+      HIP_TRY(hipMemsetAsync(s->d_stats, 0, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), M));
 
-      {  /* level 0: generate the primary rays, then their closest hits */
-         Timer &tg = ev.begin(M, &st.ms_generate);
-         hipLaunchKernelGGL(k_generate, dim3(grid_for(lv[0].n)), dim3(RT_BLOCK), 0, M, cam, g, lv[0].n, AT(QRay, lv[0].queue),
-                            AT(Hit, lv[0].hits), s->d_stats);
-         ev.end(tg, M);
-         Timer &tm = ev.begin(M, &st.ms_extend);
-         launch_trace(s, false, count, AT(QRay, lv[0].queue), (unsigned long long)lv[0].n, AT(Hit, lv[0].hits), nullptr,
-                      s->d_next + 2 * n_trace++, AT(unsigned, lv[0].slow), lds_bytes, M);
-         ev.end(tm, M); st.launches_extend++;
-         HIP_TRY(hipEventRecord(s->ev_level[0], M));
-      }
+      for (long long c = 0; c < n_chunks; c++) {
+         const int r = (int)(c % ring);
+         const long long k0 = c * chunk_tiles;
+         const long long nb = n_sel - k0 < chunk_tiles ? n_sel - k0 : chunk_tiles;
+         const long long np = nb * per_tile;
+         g.k0 = (int)k0;
+         ChunkCtr ctr = chunk_ctr(s, r);
+         QRay *queue = AT(QRay, r, o_queue);
+         Hit *hits = AT(Hit, r, o_hits);
+         SpawnRec *recs = AT(SpawnRec, r, o_recs);
 
-      int last = 0;
-      if (view != VIEW_PRIMARY) {
-         for (int l = 0; l < max_rec; l++) {
-            last = l;
-            long long n = lv[l].n;
-            int spawn = (l + 1 < max_rec) ? 1 : 0;
-            size_t live = used;           /* everything below is still needed */
-            size_t nextq_off = 0;
-            unsigned next_cap = 0;
-            if (spawn) {
-               long long cap = 2 * n;
-               if (cap > 0x7fffffffLL) { rt_set_error("ray queue too large"); return RT_ERR_TOO_LARGE; }
-               next_cap = (unsigned)cap;
-               nextq_off = carve(sizeof(QRay) * (size_t)next_cap);
-            }
-            { int rc = grow(live); if (rc != RT_OK) return rc; }
-            const QRay *queue = AT(QRay, lv[l].queue);
-            {  /* chain: the next level's rays */
-               Timer &tm = ev.begin(M, &st.ms_shade);
-               hipLaunchKernelGGL(k_spawn, dim3(grid_for(n)), dim3(RT_BLOCK), 0, M, sc, queue, (const Hit *)AT(Hit, lv[l].hits), n,
-                                  spawn, AT(SpawnRec, lv[l].recs), spawn ? AT(QRay, nextq_off) : (QRay *)nullptr,
-                                  s->d_counts + (l + 1), next_cap, s->d_stats);
-               ev.end(tm, M);
-            }
-            long long n_next = 0;
-            if (spawn) {
-               HIP_TRY(hipMemcpyAsync(s->h_counts, s->d_counts + (l + 1), sizeof(unsigned), hipMemcpyDeviceToHost, M));
-               HIP_TRY(hipStreamSynchronize(M));
-               n_next = s->h_counts[0];
-               if (n_next > next_cap) n_next = next_cap;
-               /* keep the spawned rays, release the unused queue tail */
-               used = nextq_off + align_up(sizeof(QRay) * (size_t)(n_next ? n_next : 1), 256);
-            }
-            live = used;
-            /* side: shadow rays and light sums of this level, behind its extend */
-            unsigned long long n_shadow = (unsigned long long)(L > 0 ? L : 0) * (unsigned long long)n;
-            size_t flags_off = carve((size_t)(n_shadow ? n_shadow : 1));
-            size_t shq_off = carve(sizeof(QRay) * (size_t)(n_shadow ? n_shadow : 1));
-            size_t shslow_off = carve(sizeof(unsigned) * (size_t)(n_shadow ? n_shadow : 1));
-            if (n_next > 0) {
-               lv[l + 1].n = n_next;
-               lv[l + 1].queue = nextq_off; lv[l + 1].has_queue = true;
-               carve_level(lv[l + 1]);
-            }
-            { int rc = grow(live); if (rc != RT_OK) return rc; }
-            queue = AT(QRay, lv[l].queue);
-            if (n_next > 0) {
-               /* chain first: the next extend is on the critical path */
-               Timer &tm = ev.begin(M, &st.ms_extend);
-               launch_trace(s, false, count, AT(QRay, lv[l + 1].queue), (unsigned long long)n_next, AT(Hit, lv[l + 1].hits), nullptr,
-                            s->d_next + 2 * n_trace++, AT(unsigned, lv[l + 1].slow), lds_bytes, M);
-               ev.end(tm, M); st.launches_extend++;
-               HIP_TRY(hipEventRecord(s->ev_level[l + 1], M));
-            }
-            HIP_TRY(hipStreamWaitEvent(H, s->ev_level[l], 0));
-            if (L > 0 && n > 0) {
-               Timer &ts = ev.begin(H, &st.ms_shadow_setup);
-               dim3 grid(grid_for(n), (unsigned)L);
-               hipLaunchKernelGGL(k_shadow_setup, grid, dim3(RT_BLOCK), 0, H, sc, queue, (const Hit *)AT(Hit, lv[l].hits), n,
-                                  AT(QRay, shq_off), AT(unsigned char, flags_off), s->d_stats);
-               ev.end(ts, H);
-               Timer &tm = ev.begin(H, &st.ms_shadow);
-               launch_trace(s, true, count, AT(QRay, shq_off), n_shadow, nullptr, AT(unsigned char, flags_off),
-                            s->d_next + 2 * n_trace++, AT(unsigned, shslow_off), lds_bytes, H);
-               ev.end(tm, H); st.launches_shadow++;
-            }
-            {
-               Timer &tm = ev.begin(H, &st.ms_light);
-               hipLaunchKernelGGL(k_light, dim3(grid_for(n)), dim3(RT_BLOCK), 0, H, sc, queue, (const Hit *)AT(Hit, lv[l].hits),
-                                  (const unsigned char *)AT(unsigned char, flags_off), n, p->shading, AT(float, lv[l].totals));
-               ev.end(tm, H);
-            }
-            if (n_next == 0) break;
+         /* chain stream: primaries, then the bounce forest */
+         if (c >= ring) HIP_TRY(hipStreamWaitEvent(M, s->ev_side[r], 0));     /* the slice's previous chunk is done with it */
+         HIP_TRY(hipMemsetAsync(s->d_ctr + 8 * r, 0, 8 * sizeof(unsigned long long), M));
+         {
+            Timer &tg = ev.begin(M, &st.ms_generate);
+            hipLaunchKernelGGL(k_generate, dim3(grid_for(np)), dim3(RT_BLOCK), 0, M, cam, g, np, queue, hits, recs, ctr.tail, s->d_stats);
+            ev.end(tg, M);
+            TraceArgs a; memset(&a, 0, sizeof a);
+            a.rays = queue; a.n = (unsigned long long)np; a.hits = hits; a.next = ctr.next_chain;
+            a.recs = recs; a.tail = ctr.tail; a.cap = cap; a.max_rec = max_rec;
+            Timer &tm = ev.begin(M, &st.ms_extend);
+            launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, M);
+            ev.end(tm, M); st.launches_extend++;
+            HIP_TRY(hipEventRecord(s->ev_chain[r], M));
          }
-         /* bottom-up combine once both streams are through */
-         HIP_TRY(hipEventRecord(s->ev_side_done, H));
-         HIP_TRY(hipStreamWaitEvent(M, s->ev_side_done, 0));
-         Timer &tc = ev.begin(M, &st.ms_combine);
-         for (int l = last; l >= 0; l--) {
-            const float *child = (l < last) ? AT(float, lv[l + 1].rgb) : nullptr;
-            /* the deepest level has no children: every child index is -1 there */
-            hipLaunchKernelGGL(k_combine, dim3(grid_for(lv[l].n)), dim3(RT_BLOCK), 0, M, (const SpawnRec *)AT(SpawnRec, lv[l].recs),
-                               (const float *)AT(float, lv[l].totals), child, lv[l].n, AT(float, lv[l].rgb), l == 0 ? 1 : 0);
+         if (view == VIEW_PRIMARY) {
+            hipLaunchKernelGGL(k_unslot_hits, dim3(grid_for(np)), dim3(RT_BLOCK), 0, M, g, (const Hit *)hits, np, prim_dev, t_dev);
+            HIP_TRY(hipEventRecord(s->ev_side[r], M));
+            continue;
          }
-         ev.end(tc, M);
+         /* side stream: everything that needs the chunk's hits */
+         HIP_TRY(hipStreamWaitEvent(H, s->ev_chain[r], 0));
+         if (L > 0) {
+            Timer &ts = ev.begin(H, &st.ms_shadow_setup);
+            dim3 grid(grid_for(cap), (unsigned)L);
+            hipLaunchKernelGGL(k_shadow_setup, grid, dim3(RT_BLOCK), 0, H, sc, (const QRay *)queue, (const Hit *)hits,
+                               (const unsigned *)ctr.tail, cap, AT(QRay, r, o_shq), ctr.shadow_count,
+                               AT(unsigned char, r, o_flags), s->d_stats);
+            ev.end(ts, H);
+            TraceArgs a; memset(&a, 0, sizeof a);
+            a.rays = AT(QRay, r, o_shq); a.n_dev = ctr.shadow_count; a.flags = AT(unsigned char, r, o_flags); a.next = ctr.next_shadow;
+            Timer &tm = ev.begin(H, &st.ms_shadow);
+            launch_trace(s, OUT_FLAG, count, a, (unsigned long long)n_feelers, lds_bytes, H);
+            ev.end(tm, H); st.launches_shadow++;
+         }
+         {
+            Timer &tm = ev.begin(H, &st.ms_light);
+            hipLaunchKernelGGL(k_light, dim3(grid_for(cap)), dim3(RT_BLOCK), 0, H, sc, (const QRay *)queue, (const Hit *)hits,
+                               (const unsigned char *)AT(unsigned char, r, o_flags), (const unsigned *)ctr.tail, cap, (unsigned)np,
+                               p->shading, AT(float, r, o_totals), s->d_stats);
+            ev.end(tm, H);
+            Timer &tc = ev.begin(H, &st.ms_combine);
+            hipLaunchKernelGGL(k_combine_tree, dim3(grid_for(np)), dim3(RT_BLOCK), 0, H, (const SpawnRec *)recs,
+                               (const float *)AT(float, r, o_totals), np, AT(float, r, o_rgb));
+            ev.end(tc, H);
+         }
+         if (view == VIEW_FRAME) {
+            Timer &tr = ev.begin(H, &st.ms_resolve);
+            long long npx = nb * RT_TILE * RT_TILE;
+            hipLaunchKernelGGL(k_resolve, dim3(grid_for(npx)), dim3(RT_BLOCK), 0, H, g, (const float *)AT(float, r, o_rgb), (int)nb,
+                               p->out_layout, (uchar4 *)out_dev);
+            ev.end(tr, H);
+         } else {
+            hipLaunchKernelGGL(k_unslot_rgb, dim3(grid_for(np)), dim3(RT_BLOCK), 0, H, g, (const float *)AT(float, r, o_rgb), np, rgb_dev);
+         }
+         HIP_TRY(hipEventRecord(s->ev_side[r], H));
+         HIP_TRY(hipGetLastError());
       }
-
-      if (view == VIEW_FRAME) {
-         Timer &tr = ev.begin(M, &st.ms_resolve);
-         long long npx = nb * RT_TILE * RT_TILE;
-         hipLaunchKernelGGL(k_resolve, dim3(grid_for(npx)), dim3(RT_BLOCK), 0, M, g, (const float *)AT(float, lv[0].rgb), (int)nb,
-                            p->out_layout, (uchar4 *)out_dev);
-         ev.end(tr, M);
-      } else if (view == VIEW_PRIMARY) {
-         hipLaunchKernelGGL(k_unslot_hits, dim3(grid_for(lv[0].n)), dim3(RT_BLOCK), 0, M, g, (const Hit *)AT(Hit, lv[0].hits), lv[0].n,
-                            prim_dev, t_dev);
-      } else {
-         hipLaunchKernelGGL(k_unslot_rgb, dim3(grid_for(lv[0].n)), dim3(RT_BLOCK), 0, M, g, (const float *)AT(float, lv[0].rgb), lv[0].n,
-                            rgb_dev);
-      }
+#undef AT
+      for (int r = 0; r < ring; r++) HIP_TRY(hipStreamWaitEvent(M, s->ev_side[r], 0));
+      HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipMemcpyDeviceToHost, M));
+      HIP_TRY(hipEventRecord(s->ev_end, M));
+      HIP_TRY(hipStreamWaitEvent(stream, s->ev_end, 0));
+      ev.end(t_total, stream);
+      HIP_TRY(hipStreamSynchronize(stream));
+      HIP_TRY(hipStreamSynchronize(M));
+      HIP_TRY(hipStreamSynchronize(H));
       HIP_TRY(hipGetLastError());
+      ev.collect();
+      if (sum_stat(s->h_stats, ST_ABORTED) != 0) { rt_set_error("traversal aborted: step cap or spawn list limit reached (corrupt scene?)"); return RT_ERR_HIP; }
+      /* queue entries per primary the largest chunk wanted, in sixteenths */
+      double wanted = (double)s->h_stats[ST_NODES_PER_PRIMARY_X16 * RT_STAT_REPL] / 16.0;
+      if (sum_stat(s->h_stats, ST_OVERFLOW) != 0) {
+         if (attempt >= 8) { rt_set_error("ray queue overflow persists"); return RT_ERR_TOO_LARGE; }
+         double grown = wanted * 1.25 > 2.0 * F ? wanted * 1.25 : 2.0 * F;
+         s->node_factor = (float)(grown < 64.0 ? grown : 64.0);
+         continue;                              /* some bounce rays were dropped: render the frame again */
+      }
+      if (max_rec > 1 && wanted * 1.1 > F) s->node_factor = (float)(wanted * 1.25 < 64.0 ? wanted * 1.25 : 64.0);
+      break;
    }
-   HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipMemcpyDeviceToHost, M));
-   HIP_TRY(hipEventRecord(s->ev_end, M));
-   HIP_TRY(hipStreamWaitEvent(stream, s->ev_end, 0));
-   ev.end(t_total, stream);
-   HIP_TRY(hipStreamSynchronize(stream));
-   HIP_TRY(hipStreamSynchronize(M));
-   HIP_TRY(hipStreamSynchronize(H));
-   HIP_TRY(hipGetLastError());
-   ev.collect();
-   if (sum_stat(s->h_stats, ST_ABORTED) != 0) { rt_set_error("traversal aborted: step cap reached (corrupt scene?)"); return RT_ERR_HIP; }
    st.rays_primary = sum_stat(s->h_stats, ST_PRIMARY);
    st.rays_shadow = sum_stat(s->h_stats, ST_SHADOW_TRACED);
    st.shadow_skipped = sum_stat(s->h_stats, ST_SHADOW_SKIPPED);
@@ -1529,20 +1540,21 @@ extern "C" int rt_trace_rays(const rt_scene *cs, int64_t n, const float *rays_ho
       QRay e = {r[0], r[1], r[2], to_beat_host ? to_beat_host[i] : -FLT_MAX, r[3], r[4], r[5], 1};
       q[(size_t)i] = e;
    }
-   QRay *d_q = nullptr; Hit *d_h = nullptr; unsigned *d_slow = nullptr;
+   QRay *d_q = nullptr; Hit *d_h = nullptr;
    int rc = RT_OK;
    size_t lds_bytes = 0;
    rc = trace_lds_bytes(s, &lds_bytes);
    if (rc != RT_OK) return rc;
-   if (hipMalloc((void **)&d_q, sizeof(QRay) * (size_t)n) != hipSuccess || hipMalloc((void **)&d_h, sizeof(Hit) * (size_t)n) != hipSuccess ||
-       hipMalloc((void **)&d_slow, sizeof(unsigned) * (size_t)n) != hipSuccess) {
+   if (hipMalloc((void **)&d_q, sizeof(QRay) * (size_t)n) != hipSuccess || hipMalloc((void **)&d_h, sizeof(Hit) * (size_t)n) != hipSuccess) {
       rt_set_error("rt_trace_rays: hipMalloc failed"); rc = RT_ERR_HIP;
    }
    if (rc == RT_OK) {
       (void)hipMemcpy(d_q, q.data(), sizeof(QRay) * (size_t)n, hipMemcpyHostToDevice);
       (void)hipMemset(s->d_stats, 0, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long));
-      (void)hipMemset(s->d_next, 0, 2 * sizeof(unsigned long long));
-      launch_trace(s, false, false, d_q, (unsigned long long)n, d_h, nullptr, s->d_next, d_slow, lds_bytes, 0);
+      (void)hipMemset(s->d_ctr, 0, 8 * sizeof(unsigned long long));
+      TraceArgs a; memset(&a, 0, sizeof a);
+      a.rays = d_q; a.n = (unsigned long long)n; a.hits = d_h; a.next = s->d_ctr;
+      launch_trace(s, OUT_HIT, false, a, (unsigned long long)n, lds_bytes, 0);
       std::vector<Hit> h((size_t)n);
       hipError_t e = hipMemcpy(h.data(), d_h, sizeof(Hit) * (size_t)n, hipMemcpyDeviceToHost);
       if (e != hipSuccess) { rt_set_error("rt_trace_rays: %s", hipGetErrorString(e)); rc = RT_ERR_HIP; }
@@ -1550,6 +1562,5 @@ extern "C" int rt_trace_rays(const rt_scene *cs, int64_t n, const float *rays_ho
    }
    if (d_q) (void)hipFree(d_q);
    if (d_h) (void)hipFree(d_h);
-   if (d_slow) (void)hipFree(d_slow);
    return rc;
 }
