@@ -261,16 +261,23 @@ extern __shared__ StackEntry lds_stack[];
  * view axis), and the reference's literal arithmetic when some lane holds a ray outside the exact
  * division's range (RayCtx::fast false; no ordinary scene has one).
  *
- * OUT_HIT    writes the closest hit of ray i to hits[i].
- * OUT_FLAG   shadow feelers: writes isInShadow (kernel.cu:206) to flags[valid - 1].
- * OUT_CHAIN  the whole bounce tree of the first n rays in one launch: a finished ray's reflection and
- *            refraction rays (getReflection / getRefraction, kernel.cu:209-276, guarded as in
- *            kernel.cu:361-371) are appended to the same queue behind the primaries (one atomic per wave
- *            for the indices) and traced BY THE WAVE THAT SPAWNED THEM: their indices go onto a per-wave
- *            last-in-first-out list in LDS which idle lanes drain before they fetch new primaries.  No
- *            data is handed between waves, so there is nothing to wait for and every wave's exit is
- *            its own: primaries dry, list empty, lanes idle.  valid = depth level + 1. */
-enum { OUT_HIT = 0, OUT_FLAG = 1, OUT_CHAIN = 2 };
+ * OUT_HIT    a plain queue of rays: writes the closest hit of ray i to hits[i] (toBeat early-out honoured).
+ * OUT_CHAIN  the whole shade forest of the first n rays (the primaries) in one launch.  When a ray has found
+ *            its hit, three kinds of follow-up work go onto a per-wave last-in-first-out list in LDS, which
+ *            the wave's idle lanes drain before they fetch new primaries:
+ *              - its reflection and refraction rays (getReflection / getRefraction, kernel.cu:209-276,
+ *                guarded as in kernel.cu:361-371), appended to the same queue behind the primaries (one
+ *                atomic per wave for the indices; valid = depth level + 1);
+ *              - one shadow item (isInShadow, kernel.cu:202-207, 347-352): a lane that takes it traces the
+ *                feeler of the node's next light and, while lights remain, puts the item back for another
+ *                lane.  The feeler's own-surface test (kernel.cu:351) is an ordinary leaf step: the lane
+ *                starts at the leaf of the shaded primitive in MODE_SETUP and moves to the root with the
+ *                result as its toBeat.
+ *            No data is handed between waves, so there is nothing to wait for and every wave's exit is its
+ *            own: primaries dry, list empty, lanes idle. */
+enum { OUT_HIT = 0, OUT_CHAIN = 2 };
+enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2 };
+#define RT_SHADOW_ITEM 0x80000000u
 
 #define RT_STEP_CAP (1ULL << 28)
 #define RT_REFILL_IDLE 20   /* pull new rays once this many lanes of the wave are idle */
@@ -282,11 +289,10 @@ struct TraceArgs {
    QRay *rays;                  /* the queue; OUT_CHAIN appends spawned rays behind the first n */
    unsigned long long n;        /* rays to fetch (OUT_CHAIN: the primaries) */
    const unsigned *n_dev;       /* when non-null, n is read from here instead */
-   Hit *hits;                   /* OUT_HIT, OUT_CHAIN */
-   unsigned char *flags;        /* OUT_FLAG */
+   Hit *hits;
+   unsigned char *flags;        /* OUT_CHAIN: isInShadow of (light k, queue entry i) at flags[k*cap + i] */
    unsigned long long *next;    /* this launch's zeroed fetch counter */
    unsigned long long *stats;
-   int stat_base;
    int stack_depth;             /* entries per lane of the traversal stack (the LDS behind it is the OUT_CHAIN list) */
    /* OUT_CHAIN */
    SpawnRec *recs;
@@ -328,11 +334,10 @@ __device__ __forceinline__ Ray load_qray(const QRay *q, long long i)
    return r;
 }
 
-/* one primitive test of the traversal (kernel.cu:104-134): returns true when the ray is done early */
-__device__ __forceinline__ bool leaf_test(const DScene &sc, const Ray &ray, int prim, float toBeat, float &t, int &closest,
-                                          unsigned &n_ties)
+/* what a primitive test does to the traversal state (kernel.cu:104-134): returns true when the ray is done early */
+__device__ __forceinline__ bool leaf_update(const DScene &sc, const Ray &ray, int prim, float dist, float toBeat, float &t,
+                                            int &closest, unsigned &n_ties)
 {
-   float dist = prim_intersect(sc, prim, ray);
    bool take = false;
    if (is_equal(t, dist)) {
       n_ties++;
@@ -420,18 +425,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, TraceArgs a)
    c.r.o = mk3(0, 0, 0); c.r.d = mk3(1, 1, 1); c.yx = c.yy = c.yz = 1.0f; c.par = 0; c.fast = true;
    float t = FLT_MAX, toBeat = -FLT_MAX;
    int closest = -1, cur = 0, sp = 0, tag = 0;
+   int mode = MODE_EXTEND;             /* OUT_CHAIN: what this lane's ray is */
    unsigned idx = 0;
+   unsigned n_traced = 0, n_skipped = 0;                    /* OUT_CHAIN: shadow feelers this lane traced / skipped */
    unsigned nv = 0, np = 0, nt = 0, wn = 0, wl = 0;
+   unsigned nvs = 0, nps = 0, nts = 0;                       /* COUNT only: the same for shadow feelers */
    unsigned ray_steps = 0, max_ray_steps = 0;   /* COUNT only: wave steps this ray has been in flight */
 
    /* a ray is finished: scan the planes unless it left early, write its result */
    auto finish = [&](bool early) {
       if (COUNT) { max_ray_steps = ray_steps > max_ray_steps ? ray_steps : max_ray_steps; }
       if (!early) plane_scan(sc, c.r, t, closest);
-      if (OUT == OUT_FLAG) a.flags[tag - 1] = less_than(t, toBeat) ? 1 : 0;            /* kernel.cu:206 */
-      else { Hit h; h.prim = closest; h.t = t; a.hits[idx] = h; }
       active = false;
-      if (OUT == OUT_CHAIN) pend = true;
+      if (OUT == OUT_CHAIN && mode != MODE_EXTEND) {
+         a.flags[tag - 1] = less_than(t, toBeat) ? 1 : 0;            /* kernel.cu:206 */
+      } else {
+         Hit h; h.prim = closest; h.t = t; a.hits[idx] = h;
+         if (OUT == OUT_CHAIN) pend = true;
+      }
    };
    /* pop deferred siblings until one is still closer than t (kernel.cu:160-186); none left = done */
    auto pop = [&]() {
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, TraceArgs a)
       float4 nb = *reinterpret_cast<const float4 *>(rec + 16);
       float4 nc = *reinterpret_cast<const float4 *>(rec + 32);
       int2 ch = *reinterpret_cast<const int2 *>(rec + 48);
-      if (COUNT) nv++;
+      if (COUNT) { if (OUT == OUT_CHAIN && mode != MODE_EXTEND) nvs++; else nv++; }
       float left, right;
       if (VARIANT == 2) {
          left = slab_literal(c.r, na.x, na.y, na.z, na.w, nb.x, nb.y);
@@ -491,33 +502,39 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, TraceArgs a)
          }
       }
       stat_count(stats, ST_SHADE_NODES, shaded);
-      unsigned long long mR = __ballot(want_refl), mT = __ballot(want_refr);
-      unsigned cR = __popcll(mR), cT = __popcll(mT);
-      if (cR + cT) {
-         unsigned leader = (unsigned)__ffsll((long long)(mR | mT)) - 1;
+      bool want_sh = shaded && sc.n_lights > 0;
+      unsigned long long mR = __ballot(want_refl), mT = __ballot(want_refr), mS = __ballot(want_sh);
+      unsigned cR = __popcll(mR), cT = __popcll(mT), cS = __popcll(mS);
+      if (cR + cT + cS) {
+         unsigned leader = (unsigned)__ffsll((long long)(mR | mT | mS)) - 1;
          unsigned base = 0;
-         if (lane == leader) base = atomicAdd(a.tail, cR + cT);
-         base = __shfl(base, leader);
+         if (cR + cT) {
+            if (lane == leader) base = atomicAdd(a.tail, cR + cT);
+            base = __shfl(base, leader);
+         }
          unsigned slotR = base + __popcll(mR & below), slotT = base + cR + __popcll(mT & below);
          bool okR = want_refl && slotR < a.cap, okT = want_refr && slotT < a.cap;
          unsigned long long oR = __ballot(okR), oT = __ballot(okT);
-         unsigned nOk = __popcll(oR) + __popcll(oT);
-         bool room = lifo_count + (int)nOk <= RT_LIFO_CAP;
-         if (okR) {
-            store_qray(a.rays, slotR, mk3(b.ro[0], b.ro[1], b.ro[2]), mk3(b.rd[0], b.rd[1], b.rd[2]), -FLT_MAX, tag + 1);
-            out.child_refl = (int)slotR;
-            if (room) lifo[lifo_count + __popcll(oR & below)] = slotR;
-         }
+         unsigned nR = __popcll(oR), nT = __popcll(oT);
+         bool room = lifo_count + (int)(nR + nT + cS) <= RT_LIFO_CAP;
+         /* bounce rays below, the shadow item on top: the lights are done first, the reflection's subtree before the
+          * refraction's, so the list grows with the depth of the forest and not with its size */
          if (okT) {
             store_qray(a.rays, slotT, mk3(b.to[0], b.to[1], b.to[2]), mk3(b.td[0], b.td[1], b.td[2]), -FLT_MAX, tag + 1);
             out.child_refr = (int)slotT;
-            if (room) lifo[lifo_count + __popcll(oR) + __popcll(oT & below)] = slotT;
+            if (room) lifo[lifo_count + __popcll(oT & below)] = slotT;
          }
-         if (room) lifo_count += (int)nOk;
+         if (okR) {
+            store_qray(a.rays, slotR, mk3(b.ro[0], b.ro[1], b.ro[2]), mk3(b.rd[0], b.rd[1], b.rd[2]), -FLT_MAX, tag + 1);
+            out.child_refl = (int)slotR;
+            if (room) lifo[lifo_count + nT + __popcll(oR & below)] = slotR;
+         }
+         if (want_sh && room) lifo[lifo_count + nT + nR + __popcll(mS & below)] = RT_SHADOW_ITEM | idx;   /* light 0 of entry idx */
+         if (room) lifo_count += (int)(nR + nT + cS);
          if (lane == leader) {
-            stat_add(stats, ST_REFLECT, (unsigned long long)__popcll(oR));
-            stat_add(stats, ST_REFRACT, (unsigned long long)__popcll(oT));
-            if (nOk != cR + cT) stat_add(stats, ST_OVERFLOW, 1ULL);      /* the queue is full: the host retries with a larger one */
+            if (nR) stat_add(stats, ST_REFLECT, (unsigned long long)nR);
+            if (nT) stat_add(stats, ST_REFRACT, (unsigned long long)nT);
+            if (nR + nT != cR + cT) stat_add(stats, ST_OVERFLOW, 1ULL);      /* the queue is full: the host retries with a larger one */
             if (!room) stat_add(stats, ST_ABORTED, 1ULL);
          }
       }
@@ -550,25 +567,67 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, TraceArgs a)
             base = __shfl(base, leader);
             if (base + (unsigned long long)need >= n) exhausted = true;
          }
+         unsigned item = 0;
+         bool own = !active && rank < take;
+         if (own) item = lifo[lifo_count - 1 - rank];
+         lifo_count -= take;
+         bool put_back = false;
          if (!active) {
-            bool have = false, own = false;
-            unsigned long long my = 0;
-            if (rank < take) { my = lifo[lifo_count - 1 - rank]; have = true; own = true; }
-            else if (need > 0) { my = base + (unsigned long long)(rank - take); have = my < n; }
-            if (have) {
-               QRay q = own ? load_qray_written(a.rays, my) : load_qray_rec(a.rays, my);
-               if (q.valid) {
-                  Ray r; r.o = mk3(q.ox, q.oy, q.oz); r.d = mk3(q.dx, q.dy, q.dz);
-                  c = make_ctx(r);
-                  if (!sc.fast_ok) c.fast = false;
-                  toBeat = q.to_beat; idx = (unsigned)my; tag = q.valid;
-                  t = FLT_MAX; closest = -1; sp = 0; cur = sc.root;
-                  active = true; ray_steps = 0;
-                  if (cur == RT_ROOT_EMPTY) finish(false);
+            if (OUT == OUT_CHAIN && own && (item & RT_SHADOW_ITEM)) {
+               /* the feeler of light k for queue entry `node` (PointLight.h:18-20): from the light to the shaded point */
+               unsigned code = item & ~RT_SHADOW_ITEM;
+               unsigned k = code / a.cap, node = code - k * a.cap;
+               QRay q = load_qray_written(a.rays, node);
+               unsigned long long hw = __hip_atomic_load(reinterpret_cast<unsigned long long *>(a.hits + node), __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+               int hprim = (int)(unsigned)hw; float ht = __uint_as_float((unsigned)(hw >> 32));
+               Ray ray; ray.o = mk3(q.ox, q.oy, q.oz); ray.d = mk3(q.dx, q.dy, q.dz);
+               F3 P = ray_point(ray, ht);                                    /* kernel.cu:340 */
+               const rt_dev_light &Lt = sc.lights[k];
+               Ray feeler; feeler.o = mk3(Lt.pos[0], Lt.pos[1], Lt.pos[2]); feeler.d = P - feeler.o;
+               if ((int)k + 1 < sc.n_lights) { item += a.cap; put_back = true; }     /* same entry, next light */
+               c = make_ctx(feeler);
+               if (!sc.fast_ok) c.fast = false;
+               tag = (int)code + 1; idx = node;
+               t = FLT_MAX; closest = -1; sp = 0; ray_steps = 0;
+               if (hprim >= sc.n_prims) {
+                  /* planes are not in the tree: their own-surface test is done here */
+                  float param = plane_intersect(sc, hprim - sc.n_prims, feeler);   /* kernel.cu:351 */
+                  if (param == -1.0f) { a.flags[code] = 0; n_skipped++; }
+                  else {
+                     n_traced++; toBeat = param; mode = MODE_SHADOW; cur = sc.root; active = true;
+                     if (cur == RT_ROOT_EMPTY) finish(false);
+                  }
+               } else {
+                  mode = MODE_SETUP; cur = ~hprim; toBeat = -FLT_MAX; active = true;
+               }
+            } else {
+               bool have = false;
+               unsigned long long my = 0;
+               if (own) { my = item; have = true; }
+               else if (need > 0) { my = base + (unsigned long long)(rank - take); have = my < n; }
+               if (have) {
+                  QRay q = own ? load_qray_written(a.rays, my) : load_qray_rec(a.rays, my);
+                  if (q.valid) {
+                     Ray r; r.o = mk3(q.ox, q.oy, q.oz); r.d = mk3(q.dx, q.dy, q.dz);
+                     c = make_ctx(r);
+                     if (!sc.fast_ok) c.fast = false;
+                     toBeat = q.to_beat; idx = (unsigned)my; tag = q.valid; mode = MODE_EXTEND;
+                     t = FLT_MAX; closest = -1; sp = 0; cur = sc.root;
+                     active = true; ray_steps = 0;
+                     if (cur == RT_ROOT_EMPTY) finish(false);
+                  }
                }
             }
          }
-         lifo_count -= take;
+         if (OUT == OUT_CHAIN) {
+            unsigned long long mP = __ballot(put_back);
+            if (mP) {
+               /* at most as many go back as were taken, so there is room */
+               if (put_back) lifo[lifo_count + __popcll(mP & below)] = item;
+               lifo_count += __popcll(mP);
+            }
+         }
          m_active = __ballot(active);
          wave_par = __ballot(active && c.par != 0) != 0;
          wave_lit = __ballot(active && !c.fast) != 0;
@@ -594,22 +653,47 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, TraceArgs a)
       if (__ballot(at_leaf) != 0) {
          if (COUNT) { wl++; if (active) ray_steps++; }
          if (at_leaf) {
-            if (COUNT) np++;
-            if (leaf_test(sc, c.r, ~cur, toBeat, t, closest, nt)) finish(true);
-            else pop();
+            float dist = prim_intersect(sc, ~cur, c.r);
+            if (OUT == OUT_CHAIN && mode == MODE_SETUP) {
+               /* the feeler against its own surface (kernel.cu:351).  A feeler that misses it (-1) can never be
+                * reported shadowed: isFloatLessThan(closest, -1) is false for every accepted t.  The reference
+                * still walks the tree for it; that walk is skipped here and counted separately. */
+               if (dist == -1.0f) { a.flags[tag - 1] = 0; n_skipped++; active = false; }
+               else {
+                  n_traced++; toBeat = dist; mode = MODE_SHADOW; cur = sc.root;
+                  if (cur == RT_ROOT_EMPTY) finish(false);
+               }
+            } else {
+               bool shadow = OUT == OUT_CHAIN && mode != MODE_EXTEND;
+               if (COUNT) { if (shadow) nps++; else np++; }
+               unsigned ties = 0;
+               bool early = leaf_update(sc, c.r, ~cur, dist, toBeat, t, closest, ties);
+               if (COUNT) { if (shadow) nts += ties; else nt += ties; }
+               if (early) finish(true);
+               else pop();
+            }
          }
       }
    }
+   if (OUT == OUT_CHAIN) {
+      unsigned long long m1 = __ballot(n_traced != 0), m2 = __ballot(n_skipped != 0);
+      if (m1) stat_add(stats, ST_SHADOW_TRACED, (unsigned long long)n_traced);
+      if (m2) stat_add(stats, ST_SHADOW_SKIPPED, (unsigned long long)n_skipped);
+   }
    if (COUNT) {
-      stat_add(stats, a.stat_base + 0, (unsigned long long)nv);
-      stat_add(stats, a.stat_base + 1, (unsigned long long)np);
-      stat_add(stats, a.stat_base + 2, (unsigned long long)nt);
-      if (lane == 0) {
-         stat_add(stats, a.stat_base + 3, (unsigned long long)wn);
-         stat_add(stats, a.stat_base + 4, (unsigned long long)wl);
+      stat_add(stats, ST_NODE_VISITS, (unsigned long long)nv);
+      stat_add(stats, ST_PRIM_TESTS, (unsigned long long)np);
+      stat_add(stats, ST_TIES, (unsigned long long)nt);
+      if (OUT == OUT_CHAIN) {
+         stat_add(stats, ST_NODE_VISITS_SHADOW, (unsigned long long)nvs);
+         stat_add(stats, ST_PRIM_TESTS_SHADOW, (unsigned long long)nps);
+         stat_add(stats, ST_TIES_SHADOW, (unsigned long long)nts);
       }
-      atomicMax(&stats[(a.stat_base == ST_NODE_VISITS ? ST_MAX_RAY_STEPS : ST_MAX_RAY_STEPS_SHADOW) * RT_STAT_REPL],
-                (unsigned long long)max_ray_steps);
+      if (lane == 0) {
+         stat_add(stats, ST_WAVE_NODE_STEPS, (unsigned long long)wn);
+         stat_add(stats, ST_WAVE_LEAF_STEPS, (unsigned long long)wl);
+      }
+      atomicMax(&stats[ST_MAX_RAY_STEPS * RT_STAT_REPL], (unsigned long long)max_ray_steps);
    }
 }
 
@@ -682,52 +766,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(DCamera cam, DGrid g, lon
       }
    }
    stat_count(stats, ST_PRIMARY, valid);
-}
-
-/* shadow set-up: the feeler of (light = blockIdx.y, node = x).  Feelers that have to be traced are appended
- * to a compact queue (one atomic per wave); valid - 1 is the feeler's slot in the flag array, light*cap + node.
- * The number of nodes comes from the device (the chain kernel's tail). */
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow_setup(DScene sc, const QRay *queue, const Hit *hits, const unsigned *n_dev,
-                                                           unsigned cap, QRay *shadow_queue, unsigned *shadow_count,
-                                                           unsigned char *flags, unsigned long long *stats)
-{
-   long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-   unsigned n = *n_dev < cap ? *n_dev : cap;
-   int light = blockIdx.y;
-   bool valid = false, skipped = false;
-   F3 lp = mk3(0, 0, 0), fd = mk3(0, 0, 1);
-   float param = -1.0f;
-   unsigned long long out = (unsigned long long)light * (unsigned long long)cap + (unsigned long long)i;
-   if (i < (long long)n) {
-      Hit h = hits[i];
-      if (h.prim >= 0) {
-         Ray ray = load_qray(queue, i);
-         F3 P = ray_point(ray, h.t);                                   /* kernel.cu:340 */
-         const rt_dev_light &L = sc.lights[light];
-         lp = mk3(L.pos[0], L.pos[1], L.pos[2]);
-         fd = P - lp;                                                  /* PointLight.h:18-20 */
-         Ray feeler; feeler.o = lp; feeler.d = fd;
-         param = any_intersect(sc, h.prim, feeler);                    /* kernel.cu:351 */
-         /* A feeler that misses its own surface (-1) can never be reported shadowed:
-          * isFloatLessThan(closest, -1) is false for every accepted t.  The reference still
-          * walks the tree for it; that walk is skipped here and counted separately. */
-         valid = param != -1.0f;
-         skipped = !valid;
-      }
-      if (!valid) flags[out] = 0;
-   }
-   unsigned long long m = __ballot(valid);
-   if (m) {
-      unsigned lane = __lane_id();
-      unsigned leader = (unsigned)__ffsll((long long)m) - 1;
-      unsigned base = 0;
-      if (lane == leader) base = atomicAdd(shadow_count, (unsigned)__popcll(m));
-      base = __shfl(base, leader);
-      unsigned long long below = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
-      if (valid) store_qray(shadow_queue, base + __popcll(m & below), lp, fd, param, (int)out + 1);
-   }
-   stat_count(stats, ST_SHADOW_TRACED, valid);
-   stat_count(stats, ST_SHADOW_SKIPPED, skipped);
 }
 
 /* PhongShader::shade, PhongShader.h:7-25 */
@@ -1199,8 +1237,6 @@ static int trace_lds_bytes(const rt_scene *s, size_t *out)
    if (lds_bytes > 64 * 1024) {
       HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_HIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_HIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_FLAG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_FLAG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_CHAIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_CHAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
    }
@@ -1220,17 +1256,15 @@ static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs 
       int cus = 256;
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-      g_trace_blocks = e && atoi(e) > 0 ? atoi(e) : cus * 8;
+      g_trace_blocks = e && atoi(e) > 0 ? atoi(e) : cus * 4;
    }
    unsigned long long want = (n_hint + RT_BLOCK - 1) / RT_BLOCK;
    unsigned blocks = (unsigned)(want < (unsigned long long)g_trace_blocks ? want : (unsigned long long)g_trace_blocks);
    if (blocks == 0) return;
-   a.stat_base = out_mode == OUT_FLAG ? ST_NODE_VISITS_SHADOW : ST_NODE_VISITS;
    a.stack_depth = s->host.tree_depth > 0 ? s->host.tree_depth : 1;
    a.stats = s->d_stats;
 #define RT_LAUNCH_TRACE(O, C) hipLaunchKernelGGL((k_trace<O, C>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, a)
-   if (out_mode == OUT_FLAG) { if (count) RT_LAUNCH_TRACE(OUT_FLAG, true); else RT_LAUNCH_TRACE(OUT_FLAG, false); }
-   else if (out_mode == OUT_CHAIN) { if (count) RT_LAUNCH_TRACE(OUT_CHAIN, true); else RT_LAUNCH_TRACE(OUT_CHAIN, false); }
+   if (out_mode == OUT_CHAIN) { if (count) RT_LAUNCH_TRACE(OUT_CHAIN, true); else RT_LAUNCH_TRACE(OUT_CHAIN, false); }
    else { if (count) RT_LAUNCH_TRACE(OUT_HIT, true); else RT_LAUNCH_TRACE(OUT_HIT, false); }
 #undef RT_LAUNCH_TRACE
 }
@@ -1299,7 +1333,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    for (int attempt = 0;; attempt++) {
       memset(&st, 0, sizeof st);
       /* chunk size: a chunk is bounded by its queue entries (2^24 primaries), by its shadow feelers (one
-       * 33-byte entry per light per queue entry, 2^28 of them) and wants to be a quarter of the frame or less
+       * flag byte per light per queue entry, 2^28 of them) and wants to be a quarter of the frame or less
        * so that the two streams have something to overlap, but not so small that launches dominate */
       double F = max_rec > 1 ? (double)s->node_factor : 1.0;
       long long slots_cap = max_batch_slots();
@@ -1324,7 +1358,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       const size_t o_recs = carve(sizeof(SpawnRec) * (size_t)cap), o_totals = carve(sizeof(float) * 3 * (size_t)cap);
       const size_t o_rgb = carve(sizeof(float) * 3 * (size_t)np_max);
       const size_t n_feelers = (size_t)(L > 0 ? L : 0) * (size_t)cap;
-      const size_t o_shq = carve(sizeof(QRay) * n_feelers), o_flags = carve(n_feelers);
+      const size_t o_flags = carve(n_feelers);
       const size_t slice = used;
       if (slice * (size_t)ring > s->arena.cap) { int rc = arena_reserve(s->arena, slice * (size_t)ring); if (rc != RT_OK) return rc; }
 #define AT(T, r, off) ((T *)(s->arena.base + (size_t)(r) * slice + (off)))
@@ -1336,8 +1370,11 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       HIP_TRY(hipStreamWaitEvent(M, s->ev_begin, 0));
       HIP_TRY(hipMemsetAsync(s->d_stats, 0, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), M));
 
+      HIP_TRY(hipEventRecord(s->ev_chain[0], M));                       /* the zeroed statistics */
+      if (H != M) HIP_TRY(hipStreamWaitEvent(H, s->ev_chain[0], 0));
       for (long long c = 0; c < n_chunks; c++) {
          const int r = (int)(c % ring);
+         hipStream_t S = (c & 1) ? H : M;         /* chunks alternate between the two streams */
          const long long k0 = c * chunk_tiles;
          const long long nb = n_sel - k0 < chunk_tiles ? n_sel - k0 : chunk_tiles;
          const long long np = nb * per_tile;
@@ -1347,62 +1384,46 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          Hit *hits = AT(Hit, r, o_hits);
          SpawnRec *recs = AT(SpawnRec, r, o_recs);
 
-         /* chain stream: primaries, then the bounce forest */
-         if (c >= ring) HIP_TRY(hipStreamWaitEvent(M, s->ev_side[r], 0));     /* the slice's previous chunk is done with it */
-         HIP_TRY(hipMemsetAsync(s->d_ctr + 8 * r, 0, 8 * sizeof(unsigned long long), M));
+         if (c >= ring) HIP_TRY(hipStreamWaitEvent(S, s->ev_side[r], 0));     /* the slice's previous chunk is done with it */
+         HIP_TRY(hipMemsetAsync(s->d_ctr + 8 * r, 0, 8 * sizeof(unsigned long long), S));
          {
-            Timer &tg = ev.begin(M, &st.ms_generate);
-            hipLaunchKernelGGL(k_generate, dim3(grid_for(np)), dim3(RT_BLOCK), 0, M, cam, g, np, queue, hits, recs, ctr.tail, s->d_stats);
-            ev.end(tg, M);
+            Timer &tg = ev.begin(S, &st.ms_generate);
+            hipLaunchKernelGGL(k_generate, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, cam, g, np, queue, hits, recs, ctr.tail, s->d_stats);
+            ev.end(tg, S);
             TraceArgs a; memset(&a, 0, sizeof a);
             a.rays = queue; a.n = (unsigned long long)np; a.hits = hits; a.next = ctr.next_chain;
+            a.flags = AT(unsigned char, r, o_flags);
             a.recs = recs; a.tail = ctr.tail; a.cap = cap; a.max_rec = max_rec;
-            Timer &tm = ev.begin(M, &st.ms_extend);
-            launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, M);
-            ev.end(tm, M); st.launches_extend++;
-            HIP_TRY(hipEventRecord(s->ev_chain[r], M));
+            Timer &tm = ev.begin(S, &st.ms_extend);
+            launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, S);
+            ev.end(tm, S); st.launches_extend++;
          }
          if (view == VIEW_PRIMARY) {
-            hipLaunchKernelGGL(k_unslot_hits, dim3(grid_for(np)), dim3(RT_BLOCK), 0, M, g, (const Hit *)hits, np, prim_dev, t_dev);
-            HIP_TRY(hipEventRecord(s->ev_side[r], M));
+            hipLaunchKernelGGL(k_unslot_hits, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, g, (const Hit *)hits, np, prim_dev, t_dev);
+            HIP_TRY(hipEventRecord(s->ev_side[r], S));
             continue;
          }
-         /* side stream: everything that needs the chunk's hits */
-         HIP_TRY(hipStreamWaitEvent(H, s->ev_chain[r], 0));
-         if (L > 0) {
-            Timer &ts = ev.begin(H, &st.ms_shadow_setup);
-            dim3 grid(grid_for(cap), (unsigned)L);
-            hipLaunchKernelGGL(k_shadow_setup, grid, dim3(RT_BLOCK), 0, H, sc, (const QRay *)queue, (const Hit *)hits,
-                               (const unsigned *)ctr.tail, cap, AT(QRay, r, o_shq), ctr.shadow_count,
-                               AT(unsigned char, r, o_flags), s->d_stats);
-            ev.end(ts, H);
-            TraceArgs a; memset(&a, 0, sizeof a);
-            a.rays = AT(QRay, r, o_shq); a.n_dev = ctr.shadow_count; a.flags = AT(unsigned char, r, o_flags); a.next = ctr.next_shadow;
-            Timer &tm = ev.begin(H, &st.ms_shadow);
-            launch_trace(s, OUT_FLAG, count, a, (unsigned long long)n_feelers, lds_bytes, H);
-            ev.end(tm, H); st.launches_shadow++;
-         }
          {
-            Timer &tm = ev.begin(H, &st.ms_light);
-            hipLaunchKernelGGL(k_light, dim3(grid_for(cap)), dim3(RT_BLOCK), 0, H, sc, (const QRay *)queue, (const Hit *)hits,
+            Timer &tm = ev.begin(S, &st.ms_light);
+            hipLaunchKernelGGL(k_light, dim3(grid_for(cap)), dim3(RT_BLOCK), 0, S, sc, (const QRay *)queue, (const Hit *)hits,
                                (const unsigned char *)AT(unsigned char, r, o_flags), (const unsigned *)ctr.tail, cap, (unsigned)np,
                                p->shading, AT(float, r, o_totals), s->d_stats);
-            ev.end(tm, H);
-            Timer &tc = ev.begin(H, &st.ms_combine);
-            hipLaunchKernelGGL(k_combine_tree, dim3(grid_for(np)), dim3(RT_BLOCK), 0, H, (const SpawnRec *)recs,
+            ev.end(tm, S);
+            Timer &tc = ev.begin(S, &st.ms_combine);
+            hipLaunchKernelGGL(k_combine_tree, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, (const SpawnRec *)recs,
                                (const float *)AT(float, r, o_totals), np, AT(float, r, o_rgb));
-            ev.end(tc, H);
+            ev.end(tc, S);
          }
          if (view == VIEW_FRAME) {
-            Timer &tr = ev.begin(H, &st.ms_resolve);
+            Timer &tr = ev.begin(S, &st.ms_resolve);
             long long npx = nb * RT_TILE * RT_TILE;
-            hipLaunchKernelGGL(k_resolve, dim3(grid_for(npx)), dim3(RT_BLOCK), 0, H, g, (const float *)AT(float, r, o_rgb), (int)nb,
+            hipLaunchKernelGGL(k_resolve, dim3(grid_for(npx)), dim3(RT_BLOCK), 0, S, g, (const float *)AT(float, r, o_rgb), (int)nb,
                                p->out_layout, (uchar4 *)out_dev);
-            ev.end(tr, H);
+            ev.end(tr, S);
          } else {
-            hipLaunchKernelGGL(k_unslot_rgb, dim3(grid_for(np)), dim3(RT_BLOCK), 0, H, g, (const float *)AT(float, r, o_rgb), np, rgb_dev);
+            hipLaunchKernelGGL(k_unslot_rgb, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, g, (const float *)AT(float, r, o_rgb), np, rgb_dev);
          }
-         HIP_TRY(hipEventRecord(s->ev_side[r], H));
+         HIP_TRY(hipEventRecord(s->ev_side[r], S));
          HIP_TRY(hipGetLastError());
       }
 #undef AT
