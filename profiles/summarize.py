@@ -4,8 +4,8 @@
   <tag>_bench.json            the bench.py line of the same run
   <tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats: per-kernel calls / total / average ns
   <tag>_pmc_summary.json      per-kernel sums and per-launch averages of the counters of each --pmc pass
-  traffic_trace_kernel.json   HBM-side bytes per launch of the dominant kernel (the closest-hit
-                              traversal): FETCH_SIZE doubled as the gfx950 note on that counter says
+  traffic_trace_kernel.json   HBM-side bytes per launch of the dominant kernel (the persistent
+                              traversal kernel): FETCH_SIZE doubled as the gfx950 note on that counter says
                               (it tallies 128-byte requests as 64), plus WRITE_SIZE as reported; bench.py
                               reads it into roofline.traffic
 """
@@ -18,7 +18,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = "k_trace<0"
+DOMINANT = "k_trace<2, false>"
 
 
 def short(name):
@@ -55,16 +55,16 @@ def main():
     json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     fetch = write = None
     for k, cs in summary.get("pmc_fetch", {}).items():
-        if k.startswith(DOMINANT) and "FETCH_SIZE" in cs:
+        if k.endswith(DOMINANT) and "FETCH_SIZE" in cs:
             fetch = cs["FETCH_SIZE"]["per_launch"]
     for k, cs in summary.get("pmc_write", {}).items():
-        if k.startswith(DOMINANT) and "WRITE_SIZE" in cs:
+        if k.endswith(DOMINANT) and "WRITE_SIZE" in cs:
             write = cs["WRITE_SIZE"]["per_launch"]
     if fetch is not None:
         # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB
         fetch_b = fetch * 1024 * 2
         write_b = (write or 0.0) * 1024
-        json.dump({"kernel": DOMINANT + ", false>", "tag": tag,
+        json.dump({"kernel": DOMINANT, "tag": tag,
                    "fetch_size_kib_per_launch_raw": fetch, "write_size_kib_per_launch_raw": write,
                    "correction": "FETCH_SIZE x2 (gfx950 tallies 128-byte requests as 64 bytes); WRITE_SIZE as reported; "
                                  "16-byte-per-lane gathers of 64-byte records are not the calibrated streaming pattern, "

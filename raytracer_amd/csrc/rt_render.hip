@@ -281,7 +281,7 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2 };
 
 #define RT_STEP_CAP (1ULL << 28)
 #define RT_REFILL_IDLE 20   /* pull new rays once this many lanes of the wave are idle */
-#define RT_NODE_BURST 6     /* node steps between two leaf steps / refill checks */
+#define RT_NODE_BURST 12    /* node steps between two leaf steps / refill checks */
 #define RT_LIFO_CAP 512     /* spawned rays a wave can hold back; 64 lanes x 5 spawning levels = 320 is the most a
                              * newest-first drain leaves waiting */
 
@@ -293,6 +293,7 @@ struct TraceArgs {
    unsigned char *flags;        /* OUT_CHAIN: isInShadow of (light k, queue entry i) at flags[k*cap + i] */
    unsigned long long *next;    /* this launch's zeroed fetch counter */
    unsigned long long *stats;
+   int refill_idle, node_burst; /* tuning: idle lanes that trigger a refill, node steps between two leaf steps */
    int stack_depth;             /* entries per lane of the traversal stack (the LDS behind it is the OUT_CHAIN list) */
    /* OUT_CHAIN */
    SpawnRec *recs;
@@ -405,7 +406,7 @@ __device__ __noinline__ BounceRays bounce_rays(const rt_dev_prim *prims, const r
 }
 
 template <int OUT, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, TraceArgs a)
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_trace(DScene sc, TraceArgs a)
 {
    StackEntry *stack = lds_stack + threadIdx.x;
    const int stride = RT_BLOCK;
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, TraceArgs a)
       unsigned long long m_active = __ballot(active);
       int n_idle = 64 - __popcll(m_active);
       bool any_pend = OUT == OUT_CHAIN && __ballot(pend) != 0;
-      if ((n_idle >= RT_REFILL_IDLE || m_active == 0) && (!exhausted || lifo_count > 0 || any_pend)) {
+      if ((n_idle >= a.refill_idle || m_active == 0) && (!exhausted || lifo_count > 0 || any_pend)) {
          if (any_pend) spawn_stage();
          unsigned long long m_idle = ~m_active;
          int rank = __popcll(m_idle & below);
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DScene sc, TraceArgs a)
       }
       /* ---- node steps ---- */
 #pragma unroll 1
-      for (int burst = 0; burst < RT_NODE_BURST; burst++) {
+      for (int burst = 0; burst < a.node_burst; burst++) {
          bool in_node = active && cur >= 0;
          if (__ballot(in_node) == 0) break;
          if (COUNT) { wn++; if (active) ray_steps++; }
@@ -1262,6 +1263,12 @@ static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs 
    unsigned blocks = (unsigned)(want < (unsigned long long)g_trace_blocks ? want : (unsigned long long)g_trace_blocks);
    if (blocks == 0) return;
    a.stack_depth = s->host.tree_depth > 0 ? s->host.tree_depth : 1;
+   {
+      static int refill = 0, burst = 0;
+      if (!refill) { const char *e = getenv("RT_REFILL_IDLE"); refill = e && atoi(e) > 0 ? atoi(e) : RT_REFILL_IDLE; }
+      if (!burst) { const char *e = getenv("RT_NODE_BURST"); burst = e && atoi(e) > 0 ? atoi(e) : RT_NODE_BURST; }
+      a.refill_idle = refill; a.node_burst = burst;
+   }
    a.stats = s->d_stats;
 #define RT_LAUNCH_TRACE(O, C) hipLaunchKernelGGL((k_trace<O, C>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, a)
    if (out_mode == OUT_CHAIN) { if (count) RT_LAUNCH_TRACE(OUT_CHAIN, true); else RT_LAUNCH_TRACE(OUT_CHAIN, false); }
@@ -1374,7 +1381,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       if (H != M) HIP_TRY(hipStreamWaitEvent(H, s->ev_chain[0], 0));
       for (long long c = 0; c < n_chunks; c++) {
          const int r = (int)(c % ring);
-         hipStream_t S = (c & 1) ? H : M;         /* chunks alternate between the two streams */
+         hipStream_t S = M;
          const long long k0 = c * chunk_tiles;
          const long long nb = n_sel - k0 < chunk_tiles ? n_sel - k0 : chunk_tiles;
          const long long np = nb * per_tile;
