@@ -1,0 +1,62 @@
+"""Procedural scenes for the scale configurations that have no .pov file: built in memory as SceneData,
+handed to the C ABI like any parsed scene.  Host-side data generation only (numpy); nothing here renders.
+"""
+import numpy as np
+
+from . import abi
+from .scene import SceneData, identity_modifier
+
+
+def terrain(n_x=1000, n_z=500, lights_per_side=16, seed=12345, extent=10.0):
+    """A height field of 2*n_x*n_z flat triangles under a lights_per_side^2 grid of point lights.
+
+    Quads over x, z in [-extent, extent], height 0.6 sin(0.9 x) cos(0.7 z) + 0.05 rand, two triangles per
+    quad, identity transforms, finish ambient .2 diffuse .6 specular .3 roughness .05, every 8th triangle
+    reflection .3; lights at y = 12 over the same extent, colour 1.5 / n_lights each; camera <0,9,18>
+    looking at the origin, right <1.7778,0,0>.  The defaults are the 1M-triangle / 256-light case.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    xs = np.linspace(-extent, extent, n_x + 1, dtype=np.float64)
+    zs = np.linspace(-extent, extent, n_z + 1, dtype=np.float64)
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    Y = 0.6 * np.sin(0.9 * X) * np.cos(0.7 * Z) + 0.05 * rng.random(X.shape)
+    V = np.stack([X, Y, Z], axis=-1).astype(np.float32)               # (n_x+1, n_z+1, 3)
+    a, b, c, d = V[:-1, :-1], V[1:, :-1], V[1:, 1:], V[:-1, 1:]        # quad corners
+    n_quads = n_x * n_z
+    tris = np.zeros(2 * n_quads, abi.triangle_dtype)
+    tris["p1"][0::2], tris["p2"][0::2], tris["p3"][0::2] = a.reshape(-1, 3), c.reshape(-1, 3), b.reshape(-1, 3)
+    tris["p1"][1::2], tris["p2"][1::2], tris["p3"][1::2] = a.reshape(-1, 3), d.reshape(-1, 3), c.reshape(-1, 3)
+    mod = identity_modifier(2 * n_quads)
+    mod["mat"]["clr"] = np.stack([0.35 + 0.3 * rng.random(2 * n_quads), 0.55 + 0.3 * rng.random(2 * n_quads),
+                                  0.3 + 0.2 * rng.random(2 * n_quads)], axis=-1).astype(np.float32)
+    mod["mat"]["amb"], mod["mat"]["dif"], mod["mat"]["spec"], mod["mat"]["rough"] = 0.2, 0.6, 0.3, 0.05
+    mod["mat"]["refl"][::8] = 0.3
+    tris["mod"] = mod
+    sd = SceneData()
+    sd.triangles = tris
+    n_l = lights_per_side * lights_per_side
+    lights = np.zeros(n_l, abi.light_dtype)
+    g = np.linspace(-extent, extent, lights_per_side, dtype=np.float32) if lights_per_side > 1 else np.zeros(1, np.float32)
+    LX, LZ = np.meshgrid(g, g, indexing="ij")
+    lights["pos"] = np.stack([LX.reshape(-1), np.full(n_l, 12.0, np.float32), LZ.reshape(-1)], axis=-1)
+    lights["clr"] = np.float32(1.5 / n_l)
+    sd.lights = lights
+    sd.camera = {"pos": np.array([0, 9, 18], np.float32), "up": np.array([0, 1, 0], np.float32),
+                 "right": np.array([1.7778, 0, 0], np.float32), "look_at": np.array([0, 0, 0], np.float32)}
+    return sd
+
+
+def glassy(scene: SceneData, everything=False):
+    """A copy of `scene` whose triangles (or, with `everything`, all primitives) reflect and refract
+    (reflection .3, refraction 1, ior 1.33, pigment rgbf <1,1,1,.8>): every hit spawns two rays, down to the
+    depth limit -- the bounce-queue stress."""
+    out = SceneData()
+    out.camera = scene.camera
+    for name in ("spheres", "triangles", "boxes", "smooth_triangles", "planes", "lights"):
+        setattr(out, name, getattr(scene, name).copy())
+    for name in ("triangles", "smooth_triangles") + (("spheres", "boxes", "planes") if everything else ()):
+        arr = getattr(out, name)
+        if len(arr):
+            m = arr["mod"]["mat"]
+            m["clr"], m["alpha"], m["refl"], m["refr"], m["ior"] = 1.0, 0.8, 0.3, 1.0, 1.33
+    return out

@@ -1,0 +1,73 @@
+"""Parity on the shapes of the larger configurations, at sizes the oracle finishes in seconds:
+
+  * many lights: a 10 000-triangle height field under 256 point lights (257 rays per shaded sample)
+  * full bounce trees: every surface both reflects and refracts, so a primary ray grows a binary tree of
+    depth 6 and the traversal kernel's per-wave work list sees its worst case
+  * Cook-Torrance with 4 strata per pixel on a mesh
+
+Same bars as tests/test_gpu_parity.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import orclib
+import raytracer_amd as ra
+from raytracer_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def compare(sd, w, h, samples=1, shading=abi.RT_PHONG, jitter=abi.RT_JITTER_HASH, seed=0, rgb_tol=2e-5):
+    osc = orclib.OracleScene(sd)
+    ref = osc.render(w, h, samples, shading, jitter, seed)
+    osc.close()
+    with ra.Scene(sd) as sc:
+        prim, t = sc.trace_primary(w, h, samples, jitter, seed)
+        rgb, _ = sc.render_samples(w, h, samples, shading, jitter, seed)
+        frame, st = sc.render(w, h, samples, shading, jitter, seed)
+        frame2, _ = sc.render(w, h, samples, shading, jitter, seed)
+    assert np.array_equal(prim, ref["prim"])
+    assert np.array_equal(t.view(np.uint32), ref["t"].view(np.uint32))
+    c = ref["counters"]
+    assert (st["rays_reflect"], st["rays_refract"], st["shade_nodes"]) == (c["rays_reflect"], c["rays_refract"], c["shade_nodes"])
+    assert st["rays_shadow"] + st["shadow_skipped"] == c["rays_shadow"] and st["shadow_skipped"] == c["shadow_selfmiss"]
+    both_nan = np.isnan(rgb) & np.isnan(ref["rgb"])
+    d = np.where(both_nan, 0.0, np.abs(rgb - ref["rgb"]))
+    assert not np.isnan(d).any() and d.max() <= rgb_tol, d.max()
+    diff = np.abs(frame[:, :, :3].astype(int) - ref["rgba"][:, :, :3].astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.999
+    assert frame.tobytes() == frame2.tobytes()
+    return st
+
+
+def test_256_lights():
+    st = compare(synth.terrain(100, 50), 160, 90)
+    assert st["rays_shadow"] > 200 * st["shade_nodes"]
+
+
+def test_full_binary_bounce_trees():
+    sd = synth.glassy(ra.SceneData.load(os.path.join(GOLDEN, "scenes", "dragon_large_tris.npz")))
+    st = compare(sd, 320, 180)
+    assert st["rays_reflect"] > 0 and st["rays_refract"] > 0
+    assert st["rays_reflect"] + st["rays_refract"] > st["rays_primary"]
+
+
+def test_closed_glass_room_grows_whole_trees():
+    """A closed room in which everything reflects and refracts: few rays escape, so a primary grows a tree of about ten
+    the whole 63-node tree."""
+    sd = synth.glassy(ra.SceneData.load(os.path.join(GOLDEN, "scenes", "cornell.npz")), everything=True)
+    st = compare(sd, 192, 144)
+    assert st["rays_reflect"] + st["rays_refract"] > 8 * st["rays_primary"]
+
+
+def test_glassy_height_field():
+    compare(synth.glassy(synth.terrain(60, 30, lights_per_side=2)), 256, 144)
+
+
+def test_cook_torrance_four_strata():
+    sd = ra.SceneData.load(os.path.join(GOLDEN, "scenes", "bunny.npz"))
+    compare(sd, 480, 270, samples=4, shading=abi.RT_COOK_TORRANCE, seed=5, rgb_tol=1e-3)
