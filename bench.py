@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N ranks share cuda:0 and exchange over gloo (host-staged): checks the N > 1 code path on a 1-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -100,9 +102,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     sd = ra.SceneData.load(os.path.join(ROOT, "tests", "golden", "scenes", SCENE + ".npz"))
     shading, jitter = ra.PHONG, abi.RT_JITTER_HASH
@@ -121,7 +128,11 @@ def main():
         if world == 1:
             return scene.render_device(params, frame.data_ptr(), stream)
         st = scene.render_device(params, part.data_ptr(), stream)
-        parts = tiles.gather_parts(part, world, rank, dst=0)          # the one exchange: compact tiles -> rank 0
+        if args.rehearse_on_one_gpu:
+            parts = tiles.gather_parts(part.cpu(), world, rank, dst=0)
+            parts = parts.cuda() if rank == 0 else None
+        else:
+            parts = tiles.gather_parts(part, world, rank, dst=0)      # the one exchange: compact tiles -> rank 0
         if rank == 0:
             rc = lib.rt_untile_device(parts.data_ptr(), part_bytes, world, width, height, frame.data_ptr(), stream)
             if rc != 0:
@@ -146,9 +157,10 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
+    red_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"
     rays = torch.tensor([st["rays_total"], st["rays_primary"], st["rays_shadow"], st["rays_reflect"] + st["rays_refract"]],
-                        dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                        dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
