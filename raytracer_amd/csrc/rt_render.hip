@@ -447,13 +447,23 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    };
    /* pop deferred siblings until one is still closer than t (kernel.cu:160-186); none left = done */
    auto pop = [&]() {
+      /* the first try is straight-line code (nearly always enough: an entry goes stale only when t has shrunk
+       * since it was pushed); the loop behind it walks past stale entries */
       bool found = false;
-      while (sp > 0) {
+      if (sp > 0) {
          sp--;
          StackEntry e = stack[sp * stride];
-         if (e.dist < t) { cur = e.child; found = true; break; }
+         found = e.dist < t;
+         if (found) cur = e.child;
       }
-      if (!found) finish(false);
+      if (!found) {
+         while (sp > 0) {
+            sp--;
+            StackEntry e = stack[sp * stride];
+            if (e.dist < t) { cur = e.child; found = true; break; }
+         }
+         if (!found) finish(false);
+      }
    };
    /* one node step of this lane (kernel.cu:136-158) */
    auto node_step = [&](auto variant_tag) {
@@ -473,12 +483,16 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          left = slab_fast<VARIANT == 1>(c, na.x, na.y, na.z, na.w, nb.x, nb.y);
          right = slab_fast<VARIANT == 1>(c, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w);
       }
-      /* kernel.cu:148-158 as predicates: right first on `<=`, the other child deferred if it is ahead too */
-      bool aL = above_zero(left), aR = above_zero(right);
-      bool goR = aR && (right <= left || !aL) && right < t;
-      bool goL = !goR && aL && (left <= right || !aR) && left < t;
-      if ((goR && aL) || (goL && aR)) {
-         StackEntry e; e.child = goR ? ch.x : ch.y; e.dist = goR ? left : right;
+      /* kernel.cu:148-158 as predicates.  A child that is not ahead (box value not above zero) gets distance
+       * +inf; then "right first on `<=`" is r <= l, "closer than the hit so far" is < t (t is finite or
+       * FLT_MAX), and the other child is deferred exactly when its distance is not +inf. */
+      const float inf = __builtin_inff();
+      float l = above_zero(left) ? left : inf, r = above_zero(right) ? right : inf;
+      bool goR = r <= l && r < t;
+      bool goL = !goR && l < t;
+      float other = goR ? l : r;
+      if ((goR || goL) && other < inf) {
+         StackEntry e; e.child = goR ? ch.x : ch.y; e.dist = other;
          stack[sp * stride] = e; sp++;
       }
       if (goR || goL) cur = goR ? ch.y : ch.x;
