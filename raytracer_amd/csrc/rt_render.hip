@@ -244,6 +244,51 @@ __device__ __noinline__ bool tie_prefers_new(const rt_dev_prim *prims, const rt_
 struct StackEntry { int child; float dist; };
 extern __shared__ StackEntry lds_stack[];
 
+/* ---- primary rays ------------------------------------------------------ */
+__device__ __forceinline__ unsigned hash32(unsigned x)
+{
+   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+   return x;
+}
+
+/* sample slot -> sample coordinates on the (W*s) x (H*s) grid.  A tile's samples are
+ * numbered in 8x8 patches so that 64 consecutive slots cover a compact square of the image. */
+__device__ __forceinline__ bool slot_to_sample(const DGrid &g, long long slot, int &X, int &Y)
+{
+   int per_tile = g.ts * g.ts;
+   int k = (int)(slot / per_tile);
+   int r = (int)(slot % per_tile);
+   int patch = r >> 6, lane = r & 63;
+   int px = patch % g.patches_per_row, py = patch / g.patches_per_row;
+   int sx = px * 8 + (lane & 7), sy = py * 8 + (lane >> 3);
+   int tile = g.tile_first + (g.k0 + k) * g.tile_stride;
+   int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+   X = tx * g.ts + sx; Y = ty * g.ts + sy;
+   return X < g.res_w && Y < g.res_h;
+}
+
+/* generateCameraRays, kernel.cu:477-498 */
+__device__ __forceinline__ Ray camera_ray(const DCamera &cam, const DGrid &g, int x, int y)
+{
+   float r1 = 0.5f, r2 = 0.5f;
+   if (g.jitter == RT_JITTER_HASH) {
+      unsigned index = (unsigned)(y * g.res_w + x);
+      unsigned base = hash32(index ^ (g.seed * 0x9e3779b9U));
+      unsigned h1 = hash32(base ^ 0x68bc21ebU), h2 = hash32(base ^ 0x02e5be93U);
+      r1 = (float)((h1 >> 8) + 1U) * 5.9604644775390625e-8f;   /* (0, 1], like curand_uniform */
+      r2 = (float)((h2 >> 8) + 1U) * 5.9604644775390625e-8f;
+   }
+   float uJitter = (r1 - .5f) / (float)g.res_w;
+   float vJitter = (r2 - .5f) / (float)g.res_h;
+   float u = 2.0f * ((float)x / (float)g.res_w) - 1.0f + uJitter;
+   float v = 2.0f * ((float)y / (float)g.res_h) - 1.0f + vJitter;
+   F3 rPos = (u * .5f) * cam.right + (v * .5f) * cam.up + cam.pos;
+   F3 rDir = rPos - cam.pos + cam.look_dir;
+   Ray r; r.o = rPos; r.d = rDir;
+   return r;
+}
+
+
 /* k_trace: persistent-thread closest-hit / any-hit over a ray queue.
  *
  * Lane state is one ray: (ctx, t, closest, cur, sp).  cur >= 0 is an internal node, cur < 0 a leaf
@@ -296,6 +341,8 @@ struct TraceArgs {
    int refill_idle, node_burst; /* tuning: idle lanes that trigger a refill, node steps between two leaf steps */
    int stack_depth;             /* entries per lane of the traversal stack (the LDS behind it is the OUT_CHAIN list) */
    /* OUT_CHAIN */
+   DCamera cam;                 /* the first n entries are the primaries of grid `g`: made here, on fetch */
+   DGrid g;
    SpawnRec *recs;
    unsigned *tail;              /* next free queue entry; starts at n */
    unsigned cap;                /* entries the queue has room for */
@@ -429,6 +476,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    int mode = MODE_EXTEND;             /* OUT_CHAIN: what this lane's ray is */
    unsigned idx = 0;
    unsigned n_traced = 0, n_skipped = 0;                    /* OUT_CHAIN: shadow feelers this lane traced / skipped */
+   unsigned n_primary = 0;                                  /* OUT_CHAIN: primaries this lane generated */
    unsigned nv = 0, np = 0, nt = 0, wn = 0, wl = 0;
    unsigned nvs = 0, nps = 0, nts = 0;                       /* COUNT only: the same for shadow feelers */
    unsigned ray_steps = 0, max_ray_steps = 0;   /* COUNT only: wave steps this ray has been in flight */
@@ -622,7 +670,25 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                if (own) { my = item; have = true; }
                else if (need > 0) { my = base + (unsigned long long)(rank - take); have = my < n; }
                if (have) {
-                  QRay q = own ? load_qray_written(a.rays, my) : load_qray_rec(a.rays, my);
+                  QRay q;
+                  if (own) q = load_qray_written(a.rays, my);
+                  else if (OUT == OUT_CHAIN) {
+                     /* generateCameraRays (kernel.cu:477-498) for sample slot `my`; the ray is also stored, for the
+                      * shadow items and the light sums that need it later */
+                     int X = 0, Y = 0;
+                     bool inside = slot_to_sample(a.g, (long long)my, X, Y);
+                     Ray pr; pr.o = mk3(0, 0, 0); pr.d = mk3(0, 0, 1);
+                     if (inside) pr = camera_ray(a.cam, a.g, X, Y);
+                     store_qray(a.rays, my, pr.o, pr.d, -FLT_MAX, inside ? 1 : 0);
+                     q.ox = pr.o.x; q.oy = pr.o.y; q.oz = pr.o.z; q.to_beat = -FLT_MAX;
+                     q.dx = pr.d.x; q.dy = pr.d.y; q.dz = pr.d.z; q.valid = inside ? 1 : 0;
+                     if (inside) n_primary++;
+                     else {
+                        /* a slot outside the frame: the result of a miss, no follow-up work */
+                        Hit h; h.prim = -1; h.t = FLT_MAX; a.hits[my] = h;
+                        *reinterpret_cast<float4 *>(a.recs + my) = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));
+                     }
+                  } else q = load_qray_rec(a.rays, my);
                   if (q.valid) {
                      Ray r; r.o = mk3(q.ox, q.oy, q.oz); r.d = mk3(q.dx, q.dy, q.dz);
                      c = make_ctx(r);
@@ -694,6 +760,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       unsigned long long m1 = __ballot(n_traced != 0), m2 = __ballot(n_skipped != 0);
       if (m1) stat_add(stats, ST_SHADOW_TRACED, (unsigned long long)n_traced);
       if (m2) stat_add(stats, ST_SHADOW_SKIPPED, (unsigned long long)n_skipped);
+      if (__ballot(n_primary != 0)) stat_add(stats, ST_PRIMARY, (unsigned long long)n_primary);
    }
    if (COUNT) {
       stat_add(stats, ST_NODE_VISITS, (unsigned long long)nv);
@@ -715,73 +782,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
 /* ======================================================================= */
 /* ray sources                                                              */
 /* ======================================================================= */
-__device__ __forceinline__ unsigned hash32(unsigned x)
-{
-   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-   return x;
-}
-
-/* sample slot -> sample coordinates on the (W*s) x (H*s) grid.  A tile's samples are
- * numbered in 8x8 patches so that 64 consecutive slots cover a compact square of the image. */
-__device__ __forceinline__ bool slot_to_sample(const DGrid &g, long long slot, int &X, int &Y)
-{
-   int per_tile = g.ts * g.ts;
-   int k = (int)(slot / per_tile);
-   int r = (int)(slot % per_tile);
-   int patch = r >> 6, lane = r & 63;
-   int px = patch % g.patches_per_row, py = patch / g.patches_per_row;
-   int sx = px * 8 + (lane & 7), sy = py * 8 + (lane >> 3);
-   int tile = g.tile_first + (g.k0 + k) * g.tile_stride;
-   int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
-   X = tx * g.ts + sx; Y = ty * g.ts + sy;
-   return X < g.res_w && Y < g.res_h;
-}
-
-/* generateCameraRays, kernel.cu:477-498 */
-__device__ __forceinline__ Ray camera_ray(const DCamera &cam, const DGrid &g, int x, int y)
-{
-   float r1 = 0.5f, r2 = 0.5f;
-   if (g.jitter == RT_JITTER_HASH) {
-      unsigned index = (unsigned)(y * g.res_w + x);
-      unsigned base = hash32(index ^ (g.seed * 0x9e3779b9U));
-      unsigned h1 = hash32(base ^ 0x68bc21ebU), h2 = hash32(base ^ 0x02e5be93U);
-      r1 = (float)((h1 >> 8) + 1U) * 5.9604644775390625e-8f;   /* (0, 1], like curand_uniform */
-      r2 = (float)((h2 >> 8) + 1U) * 5.9604644775390625e-8f;
-   }
-   float uJitter = (r1 - .5f) / (float)g.res_w;
-   float vJitter = (r2 - .5f) / (float)g.res_h;
-   float u = 2.0f * ((float)x / (float)g.res_w) - 1.0f + uJitter;
-   float v = 2.0f * ((float)y / (float)g.res_h) - 1.0f + vJitter;
-   F3 rPos = (u * .5f) * cam.right + (v * .5f) * cam.up + cam.pos;
-   F3 rDir = rPos - cam.pos + cam.look_dir;
-   Ray r; r.o = rPos; r.d = rDir;
-   return r;
-}
-
 /* ======================================================================= */
 /* kernels                                                                  */
 /* ======================================================================= */
-
-/* generate: the primary ray of every sample slot of the batch (slots outside the frame are invalid and get
- * the result of a miss right away) */
-__global__ __launch_bounds__(RT_BLOCK) void k_generate(DCamera cam, DGrid g, long long n, QRay *queue, Hit *hits, SpawnRec *recs,
-                                                       unsigned *tail, unsigned long long *stats)
-{
-   long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-   int X = 0, Y = 0;
-   bool valid = i < n && slot_to_sample(g, i, X, Y);
-   if (i == 0 && tail) *tail = (unsigned)n;       /* spawned rays are appended behind the primaries */
-   if (i < n) {
-      Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
-      if (valid) r = camera_ray(cam, g, X, Y);
-      store_qray(queue, (unsigned long long)i, r.o, r.d, -FLT_MAX, valid ? 1 : 0);
-      if (!valid) {
-         Hit h; h.prim = -1; h.t = FLT_MAX; hits[i] = h;
-         if (recs) *reinterpret_cast<float4 *>(recs + i) = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));
-      }
-   }
-   stat_count(stats, ST_PRIMARY, valid);
-}
 
 /* PhongShader::shade, PhongShader.h:7-25 */
 __device__ __forceinline__ F3 phong(F3 matColor, float amb, float dif, float spec, float rough, F3 eye, F3 lightDir,
@@ -1408,13 +1411,11 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          if (c >= ring) HIP_TRY(hipStreamWaitEvent(S, s->ev_side[r], 0));     /* the slice's previous chunk is done with it */
          HIP_TRY(hipMemsetAsync(s->d_ctr + 8 * r, 0, 8 * sizeof(unsigned long long), S));
          {
-            Timer &tg = ev.begin(S, &st.ms_generate);
-            hipLaunchKernelGGL(k_generate, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, cam, g, np, queue, hits, recs, ctr.tail, s->d_stats);
-            ev.end(tg, S);
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ctr.tail, (int)np, 1, S));     /* spawned rays are appended behind the primaries */
             TraceArgs a; memset(&a, 0, sizeof a);
             a.rays = queue; a.n = (unsigned long long)np; a.hits = hits; a.next = ctr.next_chain;
             a.flags = AT(unsigned char, r, o_flags);
-            a.recs = recs; a.tail = ctr.tail; a.cap = cap; a.max_rec = max_rec;
+            a.recs = recs; a.tail = ctr.tail; a.cap = cap; a.max_rec = max_rec; a.cam = cam; a.g = g;
             Timer &tm = ev.begin(S, &st.ms_extend);
             launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, S);
             ev.end(tm, S); st.launches_extend++;
