@@ -7,7 +7,8 @@ A step is one frame: generate -> extend -> shadow -> shade (per depth level) -> 
 with the scene and BVH already resident in HBM and the 8-bit frame left in HBM.  With N > 1 (one
 process per GPU, launched by torch.distributed.run) the frame is sharded by 32x32-pixel tiles, tile k
 to rank k mod N, the scene is replicated, and the compact tile buffers are gathered to rank 0 over
-RCCL and un-tiled there; that exchange is inside the timed region.  value = rays of the whole frame
+RCCL and un-tiled there.  The gather of frame k overlaps the rendering of frame k + 1 (two part buffers);
+all K gathers and un-tiles complete inside the timed region.  value = rays of the whole frame
 / max-over-ranks time.
 
   --scaling weak (default)  the frame grows with N so that every GPU keeps a 1080p frame's worth of
@@ -120,26 +121,38 @@ def main():
     layout = abi.RT_OUT_FRAME if world == 1 else abi.RT_OUT_TILES
     params = ra.make_params(width, height, SAMPLES, shading, jitter, 0, 0, rank, world, layout)
     frame = torch.zeros(height * width * 4, dtype=torch.uint8, device="cuda") if rank == 0 else None
-    part = torch.zeros(part_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
+    pipe = tiles.GatherPipeline(part_bytes, world, rank, "cuda", dst=0, host_staged=args.rehearse_on_one_gpu) if world > 1 else None
+    part = pipe.part[0] if pipe else None
     stream = torch.cuda.current_stream().cuda_stream
     lib = abi.load_library()
+    state = {"k": 0}
+
+    def finish_frame(b):
+        """Frame in buffer b: wait for its parts (stream-side), un-tile on rank 0."""
+        parts = pipe.collect(b)
+        if parts is not None and rank == 0:
+            rc = lib.rt_untile_device(parts.data_ptr(), part_bytes, world, width, height, frame.data_ptr(), stream)
+            if rc != 0:
+                raise RuntimeError(lib.rt_last_error())
 
     def step():
         if world == 1:
             return scene.render_device(params, frame.data_ptr(), stream)
-        st = scene.render_device(params, part.data_ptr(), stream)
-        if args.rehearse_on_one_gpu:
-            parts = tiles.gather_parts(part.cpu(), world, rank, dst=0)
-            parts = parts.cuda() if rank == 0 else None
-        else:
-            parts = tiles.gather_parts(part, world, rank, dst=0)      # the one exchange: compact tiles -> rank 0
-        if rank == 0:
-            rc = lib.rt_untile_device(parts.data_ptr(), part_bytes, world, width, height, frame.data_ptr(), stream)
-            if rc != 0:
-                raise RuntimeError(lib.rt_last_error())
+        # the one exchange, pipelined: frame k's compact tiles travel to rank 0 while frame k + 1 is rendered
+        b = state["k"] % 2
+        state["k"] += 1
+        finish_frame(b)                           # the frame that used this buffer two steps ago
+        st = scene.render_device(params, pipe.part[b].data_ptr(), stream)
+        pipe.submit(b)
         return st
 
+    def drain():
+        if pipe:
+            for b in (state["k"] % 2, (state["k"] + 1) % 2):
+                finish_frame(b)
+
     def fence():
+        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

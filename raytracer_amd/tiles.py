@@ -55,6 +55,42 @@ def gather_parts(part, world, rank, dst=0):
     return parts
 
 
+class GatherPipeline:
+    """Double-buffered gather of the ranks' compact tile buffers: while frame k's parts travel to `dst`, the ranks
+    already render frame k + 1 into the other buffer.  `submit(b)` starts the gather of buffer b (asynchronously on
+    a backend that can, i.e. RCCL); `collect(b)` makes the current stream wait for it and returns the gathered
+    (world * part_bytes) tensor on `dst` (None elsewhere, and None if nothing was submitted for b)."""
+
+    def __init__(self, part_bytes, world, rank, device, dst=0, host_staged=False):
+        import torch
+        self.world, self.rank, self.dst, self.host_staged = world, rank, dst, host_staged
+        self.part = [torch.zeros(part_bytes, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.parts = [torch.zeros(world * part_bytes, dtype=torch.uint8, device=device) if rank == dst else None for _ in range(2)]
+        self.work = [None, None]
+        self.pending = [False, False]
+
+    def submit(self, b):
+        import torch.distributed as dist
+        if self.host_staged:                      # rehearsal on a backend without device collectives
+            got = gather_parts(self.part[b].cpu(), self.world, self.rank, self.dst)
+            if self.rank == self.dst:
+                self.parts[b].copy_(got)
+            self.work[b] = None
+        else:
+            gl = list(self.parts[b].view(self.world, -1).unbind(0)) if self.rank == self.dst else None
+            self.work[b] = dist.gather(self.part[b], gl, dst=self.dst, async_op=True)
+        self.pending[b] = True
+
+    def collect(self, b):
+        if not self.pending[b]:
+            return None
+        if self.work[b] is not None:
+            self.work[b].wait()
+            self.work[b] = None
+        self.pending[b] = False
+        return self.parts[b]
+
+
 def untile_host(parts, part_stride_bytes, n_parts, width, height):
     """Row-major (height, width, 4) frame from `n_parts` compact tile buffers laid back to back."""
     parts = np.asarray(parts, dtype=np.uint8).reshape(-1)

@@ -103,3 +103,16 @@ def test_antialiased_vga_frame_against_oracle():
     diff = np.abs(frame[:, :, :3].astype(int) - ref["rgba"][:, :, :3].astype(int)).max(axis=2)
     assert (diff <= 1).mean() >= 0.999
     assert st["rays_primary"] == 640 * 480 * 4
+
+
+def test_chunked_frame_equals_unchunked(monkeypatch):
+    """A frame cut into many chunks (more than the arena has slices for, so slices are re-used) is the same bytes."""
+    sd = ra.SceneData.load(os.path.join(GOLDEN, "scenes", "cornell.npz"))
+    with ra.Scene(sd) as sc:
+        whole, st0 = sc.render(400, 300, 4, abi.RT_PHONG, abi.RT_JITTER_HASH)
+        monkeypatch.setenv("RT_CHUNK_TILES", "7")
+        parts, st1 = sc.render(400, 300, 4, abi.RT_PHONG, abi.RT_JITTER_HASH)
+        monkeypatch.delenv("RT_CHUNK_TILES")
+    assert st1["launches_extend"] > 8 and st0["launches_extend"] == 1
+    assert parts.tobytes() == whole.tobytes()
+    assert st0["rays_total"] == st1["rays_total"]

@@ -57,9 +57,22 @@ def _worker(rank, world, port, out_path):
         # whole-job ray count the way bench.py forms it: a sum over ranks
         mine = torch.tensor([float(len(tiles.tiles_of(W, H, rank, world)))], dtype=torch.float64)
         dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        # the double-buffered form bench.py uses: three frames in flight over two buffers, collected in order
+        pipe = tiles.GatherPipeline(tiles.part_bytes(W, H, world), world, rank, "cpu", dst=0)
+        piped_ok = True
+        frames = [frame, frame[::-1].copy(), np.roll(frame, 3, axis=1)]
+        for k, f in enumerate(frames + [None, None]):
+            b = k % 2
+            got = pipe.collect(b)
+            if got is not None and rank == 0:
+                want = frames[k - 2]
+                piped_ok &= bool((tiles.untile_host(got.numpy(), tiles.part_bytes(W, H, world), world, W, H) == want).all())
+            if f is not None:
+                pipe.part[b].copy_(torch.from_numpy(_pack(f, rank, world)))
+                pipe.submit(b)
         if rank == 0:
             got = tiles.untile_host(parts.numpy(), tiles.part_bytes(W, H, world), world, W, H)
-            np.savez(out_path, ok=np.array(bool((got == frame).all())), tiles=np.array(mine.item()),
+            np.savez(out_path, ok=np.array(bool((got == frame).all()) and piped_ok), tiles=np.array(mine.item()),
                      nonzero=np.array(int((frame[:, :, :3] != 0).sum())))
         else:
             assert parts is None
