@@ -169,7 +169,14 @@ typedef struct rt_bvh_node {
 typedef struct rt_scene rt_scene;   /* opaque: host copy + device-resident flat scene */
 
 /* scene creation flags */
-enum { RT_SCENE_DEFAULT = 0, RT_SCENE_COUNTERS = 1 };
+enum {
+   RT_SCENE_DEFAULT = 0,
+   RT_SCENE_COUNTERS = 1,    /* traversal statistics in rt_stats (a slower variant of the kernel) */
+   RT_SCENE_FAST_BVH = 2     /* NOT the reference's tree: a surface-area-heuristic BVH over the same primitives.
+                              * Far fewer box tests per ray, but near-ties between primitives (kernel.cu:108-122)
+                              * are resolved by visiting order, so a few silhouette samples differ from the
+                              * reference; never part of a parity claim */
+};
 
 /* ---- entry points ------------------------------------------------------ */
 

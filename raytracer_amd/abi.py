@@ -29,7 +29,7 @@ RT_JITTER_NONE, RT_JITTER_HASH = 0, 1
 RT_OUT_FRAME, RT_OUT_TILES = 0, 1
 RT_TILE = 32
 RT_MAX_RECURSE = 6
-RT_SCENE_DEFAULT, RT_SCENE_COUNTERS = 0, 1
+RT_SCENE_DEFAULT, RT_SCENE_COUNTERS, RT_SCENE_FAST_BVH = 0, 1, 2
 
 f32, i32 = np.float32, np.int32
 

@@ -61,7 +61,7 @@ def make_params(width, height, sample_count=1, shading=PHONG, jitter=abi.RT_JITT
 class Scene:
     """Device-resident scene: objects in the reference's creation order, its BVH, flattened (rt_scene_create)."""
 
-    def __init__(self, data: SceneData, device=0, counters=False, host_only=False):
+    def __init__(self, data: SceneData, device=0, counters=False, host_only=False, fast_bvh=False):
         self._lib = abi.load_library()
         self.data = data
         desc, keep = data.to_desc()
@@ -70,7 +70,7 @@ class Scene:
             _check(self._lib, self._lib.rt_scene_create_host(C.byref(desc), C.byref(h)))
         else:
             _check(self._lib, self._lib.rt_scene_create(C.byref(desc), device,
-                                                        abi.RT_SCENE_COUNTERS if counters else abi.RT_SCENE_DEFAULT,
+                                                        (abi.RT_SCENE_COUNTERS if counters else 0) | (abi.RT_SCENE_FAST_BVH if fast_bvh else 0),
                                                         C.byref(h)))
         self._h = h
         self.device = device

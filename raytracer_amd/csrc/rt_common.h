@@ -81,6 +81,8 @@ extern "C" {
 /* Host: objects in initScene order + reference-topology BVH + flattening.
  * Returns RT_OK or an RT_ERR_* code; on success the arrays are malloc'ed. */
 int rt_flatten_scene(const rt_scene_desc *desc, rt_flat_scene *out);
+/* flags: RT_SCENE_FAST_BVH builds the opt-in surface-area-heuristic tree instead of the reference's */
+int rt_flatten_scene_ex(const rt_scene_desc *desc, int flags, rt_flat_scene *out);
 void rt_flat_scene_free(rt_flat_scene *fs);
 void rt_set_error(const char *fmt, ...);
 #ifdef __cplusplus

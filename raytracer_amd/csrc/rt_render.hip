@@ -1090,7 +1090,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->camera = desc->camera; s->has_camera = desc->has_camera;
 
    auto t0 = std::chrono::steady_clock::now();
-   int st = rt_flatten_scene(desc, &s->host);
+   int st = rt_flatten_scene_ex(desc, flags, &s->host);
    if (st != RT_OK) { delete s; return st; }
    auto t1 = std::chrono::steady_clock::now();
    s->ms_build_host = std::chrono::duration<float, std::milli>(t1 - t0).count();

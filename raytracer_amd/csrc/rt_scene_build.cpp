@@ -22,6 +22,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -264,6 +265,95 @@ void flatten_tree(const std::vector<TreeNode> &pool, int root, std::vector<rt_bv
    *depth_out = depth;
 }
 
+/* ---- opt-in tree: binned surface-area heuristic ---------------------------
+ * NOT the reference's tree.  Same node layout, same leaves (one primitive each), so the traversal kernel is
+ * unchanged, but the visiting order differs and with it the outcome of near-ties (kernel.cu:108-122): frames
+ * made with it are reported apart from the parity numbers.  Boxes are plain unions of the (already padded)
+ * primitive boxes.  Depth is capped at ceil(log2 n) + 8 by falling back to median splits, because the
+ * traversal stack lives in LDS. */
+inline Box3 unite(const Box3 &a, const Box3 &b)
+{
+   return Box3{F3{lo(a.mn.x, b.mn.x), lo(a.mn.y, b.mn.y), lo(a.mn.z, b.mn.z)}, F3{hi(a.mx.x, b.mx.x), hi(a.mx.y, b.mx.y), hi(a.mx.z, b.mx.z)}};
+}
+inline float half_area(const Box3 &b)
+{
+   float dx = b.mx.x - b.mn.x, dy = b.mx.y - b.mn.y, dz = b.mx.z - b.mn.z;
+   return dx * dy + dy * dz + dz * dx;
+}
+inline F3 box_center(const Box3 &b) { return F3{0.5f * (b.mn.x + b.mx.x), 0.5f * (b.mn.y + b.mx.y), 0.5f * (b.mn.z + b.mx.z)}; }
+
+struct SahBuilder {
+   const std::vector<Box3> &boxes;
+   std::vector<int32_t> &ids;
+   std::vector<TreeNode> &pool;
+   enum { BINS = 16 };
+
+   int build(int first, int last, int depth_left)     /* [first, last) */
+   {
+      int n = last - first;
+      if (n == 1) { int p = ids[(size_t)first]; pool.push_back(TreeNode{-1, -1, p, boxes[(size_t)p]}); return (int)pool.size() - 1; }
+      Box3 cb; bool have = false;
+      for (int i = first; i < last; i++) {
+         F3 c = box_center(boxes[(size_t)ids[(size_t)i]]);
+         Box3 pt{c, c};
+         cb = have ? unite(cb, pt) : pt; have = true;
+      }
+      int levels_needed = 0; while ((1 << levels_needed) < n) levels_needed++;
+      int mid = -1;
+      if (depth_left > levels_needed) {
+         float best = FLT_MAX; int best_axis = -1, best_bin = -1;
+         for (int axis = 0; axis < 3; axis++) {
+            float lo_c = axis_of(cb.mn, axis), ext = axis_of(cb.mx, axis) - lo_c;
+            if (!(ext > 0.0f)) continue;
+            Box3 bb[BINS]; int cnt[BINS]; bool used[BINS];
+            for (int k = 0; k < BINS; k++) { cnt[k] = 0; used[k] = false; }
+            for (int i = first; i < last; i++) {
+               const Box3 &pb = boxes[(size_t)ids[(size_t)i]];
+               int k = (int)((axis_of(box_center(pb), axis) - lo_c) / ext * BINS); if (k >= BINS) k = BINS - 1; if (k < 0) k = 0;
+               bb[k] = used[k] ? unite(bb[k], pb) : pb; used[k] = true; cnt[k]++;
+            }
+            float right_area[BINS]; int right_cnt[BINS];
+            Box3 acc; bool ha = false; int c = 0;
+            for (int k = BINS - 1; k > 0; k--) {
+               if (used[k]) { acc = ha ? unite(acc, bb[k]) : bb[k]; ha = true; c += cnt[k]; }
+               right_area[k] = ha ? half_area(acc) : 0.0f; right_cnt[k] = c;
+            }
+            ha = false; c = 0;
+            for (int k = 0; k < BINS - 1; k++) {
+               if (used[k]) { acc = ha ? unite(acc, bb[k]) : bb[k]; ha = true; c += cnt[k]; }
+               if (c == 0 || right_cnt[k + 1] == 0) continue;
+               float cost = half_area(acc) * (float)c + right_area[k + 1] * (float)right_cnt[k + 1];
+               if (cost < best) { best = cost; best_axis = axis; best_bin = k; }
+            }
+         }
+         if (best_axis >= 0) {
+            float lo_c = axis_of(cb.mn, best_axis), ext = axis_of(cb.mx, best_axis) - lo_c;
+            int i = first, j = last - 1;
+            while (i <= j) {
+               int k = (int)((axis_of(box_center(boxes[(size_t)ids[(size_t)i]]), best_axis) - lo_c) / ext * BINS); if (k >= BINS) k = BINS - 1; if (k < 0) k = 0;
+               if (k <= best_bin) i++; else { std::swap(ids[(size_t)i], ids[(size_t)j]); j--; }
+            }
+            if (i > first && i < last) mid = i;
+         }
+      }
+      if (mid < 0) {
+         /* median split on the widest centroid axis (also the forced choice once the depth budget is tight) */
+         int axis = 0;
+         float ex = cb.mx.x - cb.mn.x, ey = cb.mx.y - cb.mn.y, ez = cb.mx.z - cb.mn.z;
+         if (ey > ex && ey >= ez) axis = 1; else if (ez > ex && ez > ey) axis = 2;
+         mid = first + n / 2;
+         std::nth_element(ids.begin() + first, ids.begin() + mid, ids.begin() + last, [&](int32_t a, int32_t b) {
+            float ca = axis_of(box_center(boxes[(size_t)a]), axis), cb2 = axis_of(box_center(boxes[(size_t)b]), axis);
+            return ca < cb2 || (ca == cb2 && a < b);
+         });
+      }
+      int l = build(first, mid, depth_left - 1);
+      int r = build(mid, last, depth_left - 1);
+      pool.push_back(TreeNode{l, r, -1, unite(pool[(size_t)l].bb, pool[(size_t)r].bb)});
+      return (int)pool.size() - 1;
+   }
+};
+
 template <class T> T *copy_out(const std::vector<T> &v)
 {
    T *p = (T *)malloc(sizeof(T) * (v.size() ? v.size() : 1));
@@ -284,7 +374,9 @@ extern "C" void rt_set_error(const char *fmt, ...)
 }
 extern "C" const char *rt_last_error(void) { return g_error; }
 
-extern "C" int rt_flatten_scene(const rt_scene_desc *d, rt_flat_scene *out)
+extern "C" int rt_flatten_scene(const rt_scene_desc *d, rt_flat_scene *out) { return rt_flatten_scene_ex(d, 0, out); }
+
+extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_scene *out)
 {
    if (!d || !out) { rt_set_error("rt_flatten_scene: null argument"); return RT_ERR_BAD_ARGUMENT; }
    if (d->n_spheres < 0 || d->n_triangles < 0 || d->n_boxes < 0 || d->n_smooth_triangles < 0 ||
@@ -341,7 +433,15 @@ extern "C" int rt_flatten_scene(const rt_scene_desc *d, rt_flat_scene *out)
    std::vector<rt_bvh_node> flat;
    int32_t root = RT_ROOT_EMPTY;
    int depth = 0;
-   if (n > 0) {
+   if (n > 0 && (flags & RT_SCENE_FAST_BVH)) {
+      std::vector<TreeNode> pool;
+      pool.reserve((size_t)(2 * n));
+      int levels = 0; while ((1 << levels) < n) levels++;
+      SahBuilder sb{b.boxes, order, pool};
+      int root_node = sb.build(0, n, levels + 8);
+      if (pool[(size_t)root_node].prim >= 0) root = ~pool[(size_t)root_node].prim;
+      else { flatten_tree(pool, root_node, flat, &depth); root = 0; }
+   } else if (n > 0) {
       /* the sort rounds of formBVH (bvh.cpp:46-72).  A range is (first, second);
        * the left half is queued as (start, pow2) -- NOT (start, start + pow2) --
        * exactly as bvh.cpp:65 does, so it is empty (and skipped, bvh.cpp:126)
