@@ -165,7 +165,7 @@ def main():
     acc = {}
     for _ in range(args.steps):
         st = step()
-        for k in ("ms_total", "ms_extend", "ms_shadow", "ms_shade", "ms_combine", "ms_resolve"):
+        for k in ("ms_total", "ms_trace", "ms_light", "ms_combine", "ms_resolve"):
             acc[k] = acc.get(k, 0.0) + st[k]
     fence()
     dt = time.perf_counter() - t0
@@ -193,8 +193,8 @@ def main():
         counted.close()
         b_extend, b_shadow = algorithmic_bytes(cst)
         # one persistent launch traces every ray of the frame (bounce rays and shadow feelers alike)
-        launches = max(1, st["launches_extend"])
-        avg_ms = acc["ms_extend"] / args.steps / launches
+        launches = max(1, st["launches_trace"])
+        avg_ms = acc["ms_trace"] / args.steps / launches
         bytes_per_launch = (b_extend + b_shadow) / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None

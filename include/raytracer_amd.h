@@ -129,22 +129,22 @@ typedef struct rt_stats {
    uint64_t shadow_skipped;     /* shadow feelers whose self-test missed: the reference still walks the tree for them, the outcome is always "lit" */
    uint64_t shade_nodes;        /* shadeObject invocations */
    uint64_t samples;
-   /* device time, ms (HIP events).  ms_total spans the frame on the caller's stream; the per-kernel sums
-    * are taken on the library's two internal streams, which overlap, so they can add up to more than it */
-   float ms_total;              /* first launch -> resolve completion */
-   float ms_extend, ms_shadow, ms_shade, ms_combine, ms_resolve;   /* extend / shadow: the traversal launches alone */
-   float ms_generate, ms_shadow_setup, ms_light;   /* ms_shade: the spawn half of shading; ms_light: the light sums */
-   int32_t launches_extend, launches_shadow;
+   /* device time, ms (HIP events on the stream the kernels run on) */
+   float ms_total;              /* the whole frame, bracketed on the caller's stream */
+   float ms_trace;              /* the persistent traversal launches (one per chunk of tiles) */
+   float ms_light, ms_combine, ms_resolve;
+   int32_t launches_trace;      /* = chunks the frame was cut into */
+   int32_t attempts;            /* > 1: the ray queue overflowed, was grown, and the frame was rendered again */
    /* traversal work counters (only filled when the scene was created with RT_SCENE_COUNTERS):
-    * 64-byte node records fetched, primitive records tested, near-tie events -- for the
-    * extend launches and for the shadow launches */
+    * 64-byte node records fetched, primitive records tested, near-tie events -- for the closest-hit rays
+    * (primary, reflection, refraction) and for the shadow feelers */
    uint64_t node_visits, prim_tests, tie_events;
    uint64_t node_visits_shadow, prim_tests_shadow, tie_events_shadow;
    /* wave-level step counts (one per wave per executed node step / leaf step): lane utilisation of
-    * the traversal loop = node_visits / (64 * wave_node_steps) */
-   uint64_t wave_node_steps, wave_leaf_steps, wave_node_steps_shadow, wave_leaf_steps_shadow;
-   /* the longest single ray, in wave steps it was in flight: the serial floor of a traversal launch */
-   uint64_t max_ray_steps, max_ray_steps_shadow;
+    * the traversal loop = (node_visits + node_visits_shadow) / (64 * wave_node_steps) */
+   uint64_t wave_node_steps, wave_leaf_steps;
+   /* the longest single ray, in wave steps it was in flight */
+   uint64_t max_ray_steps;
 } rt_stats;
 
 typedef struct rt_scene_info {

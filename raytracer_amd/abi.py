@@ -77,15 +77,13 @@ class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
                 ("rays_refract", C.c_uint64), ("rays_total", C.c_uint64), ("shadow_skipped", C.c_uint64),
                 ("shade_nodes", C.c_uint64), ("samples", C.c_uint64),
-                ("ms_total", C.c_float), ("ms_extend", C.c_float), ("ms_shadow", C.c_float),
-                ("ms_shade", C.c_float), ("ms_combine", C.c_float), ("ms_resolve", C.c_float),
-                ("ms_generate", C.c_float), ("ms_shadow_setup", C.c_float), ("ms_light", C.c_float),
-                ("launches_extend", C.c_int32), ("launches_shadow", C.c_int32),
+                ("ms_total", C.c_float), ("ms_trace", C.c_float), ("ms_light", C.c_float),
+                ("ms_combine", C.c_float), ("ms_resolve", C.c_float),
+                ("launches_trace", C.c_int32), ("attempts", C.c_int32),
                 ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64), ("tie_events", C.c_uint64),
                 ("node_visits_shadow", C.c_uint64), ("prim_tests_shadow", C.c_uint64), ("tie_events_shadow", C.c_uint64),
                 ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64),
-                ("wave_node_steps_shadow", C.c_uint64), ("wave_leaf_steps_shadow", C.c_uint64),
-                ("max_ray_steps", C.c_uint64), ("max_ray_steps_shadow", C.c_uint64)]
+                ("max_ray_steps", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

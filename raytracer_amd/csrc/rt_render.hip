@@ -92,8 +92,8 @@ struct SpawnRec {
 
 enum { ST_SHADOW_TRACED = 0, ST_SHADOW_SKIPPED, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES, ST_PRIMARY,
        ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
-       ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_WAVE_NODE_STEPS_SHADOW, ST_WAVE_LEAF_STEPS_SHADOW,
-       ST_ABORTED, ST_MAX_RAY_STEPS, ST_MAX_RAY_STEPS_SHADOW, ST_OVERFLOW, ST_NODES_PER_PRIMARY_X16, ST_COUNT };
+       ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW,
+       ST_ABORTED, ST_MAX_RAY_STEPS, ST_OVERFLOW, ST_NODES_PER_PRIMARY_X16, ST_COUNT };
 
 /* Statistics counters are replicated RT_STAT_REPL times (blocks spread over the replicas, the host
  * sums them) and bumped once per wave, so that counting does not serialise the kernels on one word. */
@@ -1354,8 +1354,10 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    hipStream_t M = s->chain, H = s->side;
    { const char *e = getenv("RT_SINGLE_STREAM"); if (e && atoi(e)) H = M; }
 
+   int attempts = 0;
    for (int attempt = 0;; attempt++) {
       memset(&st, 0, sizeof st);
+      attempts = attempt + 1;
       /* chunk size: a chunk is bounded by its queue entries (2^24 primaries), by its shadow feelers (one
        * flag byte per light per queue entry, 2^28 of them) and wants to be a quarter of the frame or less
        * so that the two streams have something to overlap, but not so small that launches dominate */
@@ -1416,9 +1418,9 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             a.rays = queue; a.n = (unsigned long long)np; a.hits = hits; a.next = ctr.next_chain;
             a.flags = AT(unsigned char, r, o_flags);
             a.recs = recs; a.tail = ctr.tail; a.cap = cap; a.max_rec = max_rec; a.cam = cam; a.g = g;
-            Timer &tm = ev.begin(S, &st.ms_extend);
+            Timer &tm = ev.begin(S, &st.ms_trace);
             launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, S);
-            ev.end(tm, S); st.launches_extend++;
+            ev.end(tm, S); st.launches_trace++;
          }
          if (view == VIEW_PRIMARY) {
             hipLaunchKernelGGL(k_unslot_hits, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, g, (const Hit *)hits, np, prim_dev, t_dev);
@@ -1483,8 +1485,8 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    st.node_visits_shadow = sum_stat(s->h_stats, ST_NODE_VISITS_SHADOW); st.prim_tests_shadow = sum_stat(s->h_stats, ST_PRIM_TESTS_SHADOW);
    st.tie_events_shadow = sum_stat(s->h_stats, ST_TIES_SHADOW);
    st.wave_node_steps = sum_stat(s->h_stats, ST_WAVE_NODE_STEPS); st.wave_leaf_steps = sum_stat(s->h_stats, ST_WAVE_LEAF_STEPS);
-   st.max_ray_steps = s->h_stats[ST_MAX_RAY_STEPS * RT_STAT_REPL]; st.max_ray_steps_shadow = s->h_stats[ST_MAX_RAY_STEPS_SHADOW * RT_STAT_REPL];
-   st.wave_node_steps_shadow = sum_stat(s->h_stats, ST_WAVE_NODE_STEPS_SHADOW); st.wave_leaf_steps_shadow = sum_stat(s->h_stats, ST_WAVE_LEAF_STEPS_SHADOW);
+   st.max_ray_steps = s->h_stats[ST_MAX_RAY_STEPS * RT_STAT_REPL];
+   st.attempts = attempts;
    if (stats_out) *stats_out = st;
    return RT_OK;
 }

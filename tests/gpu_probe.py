@@ -23,8 +23,8 @@ with ra.Scene(sd, fast_bvh=fast) as sc:
         if i and (best is None or st["ms_total"] < best["ms_total"]):
             best = st
     st = best
-    print(f"{name} {w}x{h} spp{samples}: ms_total {st['ms_total']:.3f}  trace {st['ms_extend']:.3f} ({st['launches_extend']} launches)  "
-          f"gen {st['ms_generate']:.3f} light {st['ms_light']:.3f} combine {st['ms_combine']:.3f} resolve {st['ms_resolve']:.3f}  "
+    print(f"{name} {w}x{h} spp{samples}: ms_total {st['ms_total']:.3f}  trace {st['ms_trace']:.3f} ({st['launches_trace']} launches)  "
+          f"light {st['ms_light']:.3f} combine {st['ms_combine']:.3f} resolve {st['ms_resolve']:.3f}  "
           f"rays {st['rays_total']} -> {st['rays_total'] / st['ms_total'] / 1e3:.1f} Mrays/s")
 with ra.Scene(sd, counters=True, fast_bvh=fast) as sc:
     frame, st = sc.render(w, h, samples, shading, abi.RT_JITTER_HASH)

@@ -113,6 +113,6 @@ def test_chunked_frame_equals_unchunked(monkeypatch):
         monkeypatch.setenv("RT_CHUNK_TILES", "7")
         parts, st1 = sc.render(400, 300, 4, abi.RT_PHONG, abi.RT_JITTER_HASH)
         monkeypatch.delenv("RT_CHUNK_TILES")
-    assert st1["launches_extend"] > 8 and st0["launches_extend"] == 1
+    assert st1["launches_trace"] > 8 and st0["launches_trace"] == 1
     assert parts.tobytes() == whole.tobytes()
     assert st0["rays_total"] == st1["rays_total"]
