@@ -133,6 +133,10 @@ typedef struct rt_stats {
    float ms_total;              /* the whole frame, bracketed on the caller's stream */
    float ms_trace;              /* the persistent traversal launches (one per chunk of tiles) */
    float ms_light, ms_combine, ms_resolve;
+   /* RT_SCENE_COUNTERS, single-chunk frames: when the waves of the traversal launch finished, measured from the
+    * first wave's start (mean over waves, and the last one).  last >> mean = the launch is mostly its tail:
+    * a few waves finishing long dependent bounce chains */
+   float wave_exit_mean_ms, wave_exit_last_ms;
    int32_t launches_trace;      /* = chunks the frame was cut into */
    int32_t attempts;            /* > 1: the ray queue overflowed, was grown, and the frame was rendered again */
    /* traversal work counters (only filled when the scene was created with RT_SCENE_COUNTERS):

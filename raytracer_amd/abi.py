@@ -79,6 +79,7 @@ class Stats(C.Structure):
                 ("shade_nodes", C.c_uint64), ("samples", C.c_uint64),
                 ("ms_total", C.c_float), ("ms_trace", C.c_float), ("ms_light", C.c_float),
                 ("ms_combine", C.c_float), ("ms_resolve", C.c_float),
+                ("wave_exit_mean_ms", C.c_float), ("wave_exit_last_ms", C.c_float),
                 ("launches_trace", C.c_int32), ("attempts", C.c_int32),
                 ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64), ("tie_events", C.c_uint64),
                 ("node_visits_shadow", C.c_uint64), ("prim_tests_shadow", C.c_uint64), ("tie_events_shadow", C.c_uint64),

@@ -93,7 +93,8 @@ struct SpawnRec {
 enum { ST_SHADOW_TRACED = 0, ST_SHADOW_SKIPPED, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES, ST_PRIMARY,
        ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
        ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW,
-       ST_ABORTED, ST_MAX_RAY_STEPS, ST_OVERFLOW, ST_NODES_PER_PRIMARY_X16, ST_COUNT };
+       ST_ABORTED, ST_MAX_RAY_STEPS, ST_OVERFLOW, ST_NODES_PER_PRIMARY_X16,
+       ST_CLOCK_FIRST_START, ST_CLOCK_LAST_EXIT, ST_CLOCK_EXIT_SUM, ST_WAVES, ST_COUNT };
 
 /* Statistics counters are replicated RT_STAT_REPL times (blocks spread over the replicas, the host
  * sums them) and bumped once per wave, so that counting does not serialise the kernels on one word. */
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    int lifo_count = 0;                 /* wave-uniform */
    const unsigned long long n = a.n_dev ? (unsigned long long)*a.n_dev : a.n;
    unsigned long long *const stats = a.stats;
+   const unsigned long long clock_start = COUNT ? wall_clock64() : 0ULL;     /* 100 MHz */
 
    bool active = false;
    bool pend = false;                  /* OUT_CHAIN: finished, its bounce rays not spawned yet */
@@ -776,6 +778,15 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          stat_add(stats, ST_WAVE_LEAF_STEPS, (unsigned long long)wl);
       }
       atomicMax(&stats[ST_MAX_RAY_STEPS * RT_STAT_REPL], (unsigned long long)max_ray_steps);
+      if (lane == 0) {
+         /* when the waves of the launch were done: the mean against the last one shows how much of the launch
+          * is its tail (a few waves finishing long dependent chains) */
+         unsigned long long now = wall_clock64();
+         atomicMax(&stats[ST_CLOCK_FIRST_START * RT_STAT_REPL], ~clock_start);
+         atomicMax(&stats[ST_CLOCK_LAST_EXIT * RT_STAT_REPL], now);
+         stat_add(stats, ST_CLOCK_EXIT_SUM, now);
+         stat_add(stats, ST_WAVES, 1ULL);
+      }
    }
 }
 
@@ -1487,6 +1498,12 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    st.wave_node_steps = sum_stat(s->h_stats, ST_WAVE_NODE_STEPS); st.wave_leaf_steps = sum_stat(s->h_stats, ST_WAVE_LEAF_STEPS);
    st.max_ray_steps = s->h_stats[ST_MAX_RAY_STEPS * RT_STAT_REPL];
    st.attempts = attempts;
+   if (count && sum_stat(s->h_stats, ST_WAVES) > 0 && st.launches_trace == 1) {
+      double first = (double)(~s->h_stats[ST_CLOCK_FIRST_START * RT_STAT_REPL]);
+      double waves = (double)sum_stat(s->h_stats, ST_WAVES);
+      st.wave_exit_mean_ms = (float)(((double)sum_stat(s->h_stats, ST_CLOCK_EXIT_SUM) / waves - first) * 1e-5);
+      st.wave_exit_last_ms = (float)(((double)s->h_stats[ST_CLOCK_LAST_EXIT * RT_STAT_REPL] - first) * 1e-5);
+   }
    if (stats_out) *stats_out = st;
    return RT_OK;
 }

@@ -1,0 +1,35 @@
+"""Ad-hoc (not a test): frame times of the larger BASELINE configurations' stand-ins on one GPU."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracer_amd as ra
+from raytracer_amd import abi, synth
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes")
+
+
+def run(label, sd, w, h, spp, shading, fast=False):
+    t0 = time.time()
+    with ra.Scene(sd, fast_bvh=fast) as sc:
+        info = sc.info()
+        best = None
+        for i in range(3):
+            _, st = sc.render(w, h, spp, shading, abi.RT_JITTER_HASH)
+            if i and (best is None or st["ms_total"] < best["ms_total"]):
+                best = st
+    st = best
+    print(f"{label}: {w}x{h} spp{spp} {'fast-tree ' if fast else ''}build {info['ms_build_host']:.0f} ms, frame {st['ms_total']:.2f} ms, "
+          f"{st['rays_total'] / 1e6:.1f} Mrays -> {st['rays_total'] / st['ms_total'] / 1e3:.0f} Mrays/s, chunks {st['launches_trace']}, "
+          f"attempts {st['attempts']}  (wall {time.time() - t0:.1f} s)", flush=True)
+
+
+bunny = ra.SceneData.load(os.path.join(G, "bunny.npz"))
+dragon = ra.SceneData.load(os.path.join(G, "dragon_large_tris.npz"))
+run("config 3 stand-in A (bunny, Cook-Torrance, 4 strata)", bunny, 1920, 1080, 4, abi.RT_COOK_TORRANCE)
+run("config 4 stand-in (glassy dragon, depth 6)", synth.glassy(dragon), 3840, 2160, 1, abi.RT_PHONG)
+run("iceBot 4K", ra.SceneData.load(os.path.join(G, "iceBot.npz")), 3840, 2160, 1, abi.RT_PHONG)
+if len(sys.argv) > 1:
+    big = synth.terrain(1000, 500)
+    run("config 5 (1M triangles, 256 lights), fast tree only", big, 3840, 2160, 1, abi.RT_PHONG, fast=True)

@@ -34,3 +34,4 @@ with ra.Scene(sd, counters=True, fast_bvh=fast) as sc:
           f"shadow: visits/ray {st['node_visits_shadow'] / max(1, st['rays_shadow']):.1f} prim/ray {st['prim_tests_shadow'] / max(1, st['rays_shadow']):.2f}")
     print(f"  wave steps: node {st['wave_node_steps']} leaf {st['wave_leaf_steps']}  lane-util node {nv / max(1, 64 * st['wave_node_steps']):.3f} "
           f"leaf {(npr + st['rays_shadow'] + st['shadow_skipped']) / max(1, 64 * st['wave_leaf_steps']):.3f}  max-ray-steps {st['max_ray_steps']}")
+    print(f"  counted launch {st['ms_trace']:.3f} ms: waves done at mean {st['wave_exit_mean_ms']:.3f} ms, last {st['wave_exit_last_ms']:.3f} ms")
