@@ -75,7 +75,7 @@ typedef struct rt_material {
    float clr[3];
    float alpha;      /* pigment filter (rgbf 4th component) */
    float amb, dif, spec, rough, refl, refr, ior;
-   int32_t tex_id;   /* -1 = untextured; anything else is RT_ERR_UNSUPPORTED */
+   int32_t tex_id;   /* -1 = untextured (NO_TEXTURE, Material.h); else an index into rt_scene_desc.textures */
 } rt_material;
 
 /* TKModifier (TokenData.h:46-51) with pigment+finish folded into rt_material. */
@@ -86,16 +86,32 @@ typedef struct rt_modifier {
 } rt_modifier;
 
 typedef struct rt_sphere   { float c[3]; float r; rt_modifier mod; } rt_sphere;              /* TKSphere   TokenData.h:65-69 */
-typedef struct rt_triangle { float p1[3], p2[3], p3[3]; rt_modifier mod; } rt_triangle;     /* TKTriangle TokenData.h:83-87 (UVs dropped) */
+typedef struct rt_triangle {                                                                /* TKTriangle TokenData.h:83-87 */
+   float p1[3], p2[3], p3[3];
+   float vt1[2], vt2[2], vt3[2];   /* texture coordinates per vertex (zero when the scene gives none) */
+   rt_modifier mod;
+} rt_triangle;
 typedef struct rt_box      { float p1[3], p2[3]; rt_modifier mod; } rt_box;                 /* TKBox      TokenData.h:60-63 */
 typedef struct rt_smooth_triangle {                                                         /* TKSmoothTriangle TokenData.h:89-94 */
    float p1[3], p2[3], p3[3];
    float n1[3], n2[3], n3[3];
+   float vt1[2], vt2[2], vt3[2];
    rt_modifier mod;
 } rt_smooth_triangle;
 typedef struct rt_plane    { float n[3]; float d; rt_modifier mod; } rt_plane;              /* TKPlane    TokenData.h:71-75 */
 typedef struct rt_light    { float pos[3]; float clr[3]; } rt_light;                        /* TKPointLight TokenData.h:53-58 */
 typedef struct rt_camera   { float pos[3], up[3], right[3], look_at[3]; } rt_camera;        /* TKCamera   TokenData.h:11-17 */
+
+/* An image for pigment { image_map "file" } (POVRayParser.cpp:491-503, kernel.cu:32-64, 579-598).
+ * rgba: width*height texels of 4 bytes (r, g, b, 0), row 0 = the first row stored in the .bmp, i.e. the
+ * bottom row of the picture.  A description returned by rt_parse_pov carries the names only (rgba NULL):
+ * attach the pixels with rt_load_bmp before rt_scene_create.  The reference itself ignores the name and
+ * binds "blitz.bmp" from the working directory to every textured primitive. */
+typedef struct rt_texture {
+   int32_t width, height;
+   uint8_t *rgba;
+   char name[128];
+} rt_texture;
 
 typedef struct rt_scene_desc {
    rt_camera camera;
@@ -106,6 +122,7 @@ typedef struct rt_scene_desc {
    int32_t n_smooth_triangles; const rt_smooth_triangle *smooth_triangles;
    int32_t n_planes;           const rt_plane *planes;
    int32_t n_lights;           const rt_light *lights;
+   int32_t n_textures;         rt_texture *textures;
 } rt_scene_desc;
 
 /* ---- render parameters / statistics ------------------------------------ */
@@ -258,6 +275,10 @@ int rt_render_samples(const rt_scene *scene, const rt_render_params *params,
  * The returned description owns its arrays; free with rt_scene_desc_free. */
 int rt_parse_pov(const char *path, rt_scene_desc **out);
 void rt_scene_desc_free(rt_scene_desc *desc);
+
+/* readBMP (kernel.cu:35-61): a 24-bit uncompressed .bmp into tex->width/height/rgba (malloc'ed; a description
+ * from rt_parse_pov frees it in rt_scene_desc_free, any other owner frees it with free()). */
+int rt_load_bmp(const char *path, rt_texture *tex);
 
 /* 24-bit uncompressed TGA exactly as the reference's driver + Image::WriteTga
  * produce it from the uchar4 frame (raytrace.cpp:44-55, Image.cpp:38-101). */

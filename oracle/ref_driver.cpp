@@ -29,6 +29,7 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <map>
 #include <string>
 
 #include "POVRayParser.h"
@@ -47,6 +48,7 @@
 namespace {
 
 void put3(float *dst, const glm::vec3 &v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
+void put2(float *dst, const glm::vec2 &v) { dst[0] = v.x; dst[1] = v.y; }
 glm::vec3 get3(const float *p) { return glm::vec3(p[0], p[1], p[2]); }
 
 void put_mat(float *dst, const glm::mat4 &m)
@@ -114,6 +116,7 @@ int ref_parse_pov(const char *path, rt_scene_desc **out)
    rt_triangle *tr = (rt_triangle *)calloc(d->n_triangles + 1, sizeof(rt_triangle));
    for (int i = 0; i < d->n_triangles; i++) {
       put3(tr[i].p1, data.triangles[i].p1); put3(tr[i].p2, data.triangles[i].p2); put3(tr[i].p3, data.triangles[i].p3);
+      put2(tr[i].vt1, data.triangles[i].vt1); put2(tr[i].vt2, data.triangles[i].vt2); put2(tr[i].vt3, data.triangles[i].vt3);
       put_mod(&tr[i].mod, data.triangles[i].mod);
    }
    d->triangles = tr;
@@ -127,6 +130,7 @@ int ref_parse_pov(const char *path, rt_scene_desc **out)
       const TKSmoothTriangle &t = data.smoothTriangles[i];
       put3(st[i].p1, t.p1); put3(st[i].p2, t.p2); put3(st[i].p3, t.p3);
       put3(st[i].n1, t.n1); put3(st[i].n2, t.n2); put3(st[i].n3, t.n3);
+      put2(st[i].vt1, t.vt1); put2(st[i].vt2, t.vt2); put2(st[i].vt3, t.vt3);
       put_mod(&st[i].mod, t.mod);
    }
    d->smooth_triangles = st;
@@ -138,6 +142,13 @@ int ref_parse_pov(const char *path, rt_scene_desc **out)
    rt_light *li = (rt_light *)calloc(d->n_lights + 1, sizeof(rt_light));
    for (int i = 0; i < d->n_lights; i++) { put3(li[i].pos, data.pointLights[i].pos); put3(li[i].clr, data.pointLights[i].clr); }
    d->lights = li;
+   d->n_textures = (int)data.textureMap.size();
+   d->textures = (rt_texture *)calloc(d->n_textures + 1, sizeof(rt_texture));
+   for (std::map<std::string, int>::const_iterator it = data.textureMap.begin(); it != data.textureMap.end(); ++it) {
+      std::string name = it->first;          /* the parser's "%s" keeps the closing quote */
+      while (!name.empty() && (name[name.size() - 1] == '"' || name[name.size() - 1] == '}')) name.erase(name.size() - 1);
+      snprintf(d->textures[it->second].name, sizeof d->textures[it->second].name, "%s", name.c_str());
+   }
    *out = d;
    return 0;
 }
@@ -147,6 +158,7 @@ void ref_scene_desc_free(rt_scene_desc *d)
    if (!d) return;
    free((void *)d->spheres); free((void *)d->triangles); free((void *)d->boxes);
    free((void *)d->smooth_triangles); free((void *)d->planes); free((void *)d->lights);
+   free(d->textures);
    free(d);
 }
 
@@ -165,7 +177,8 @@ void *ref_scene_create(const rt_scene_desc *d)
    for (int i = 0; i < d->n_triangles; i++) {
       const rt_triangle &t = d->triangles[i];
       s->geomList.push_back(new Triangle(get3(t.p1), get3(t.p2), get3(t.p3), make_material(t.mod.mat),
-                                         get_mat(t.mod.trans), get_mat(t.mod.inv_trans)));
+                                         get_mat(t.mod.trans), get_mat(t.mod.inv_trans),
+                                         glm::vec2(t.vt1[0], t.vt1[1]), glm::vec2(t.vt2[0], t.vt2[1]), glm::vec2(t.vt3[0], t.vt3[1])));
    }
    for (int i = 0; i < d->n_boxes; i++) {
       const rt_box &b = d->boxes[i];
@@ -175,7 +188,7 @@ void *ref_scene_create(const rt_scene_desc *d)
       const rt_smooth_triangle &t = d->smooth_triangles[i];
       s->geomList.push_back(new SmoothTriangle(get3(t.p1), get3(t.p2), get3(t.p3), get3(t.n1), get3(t.n2), get3(t.n3),
                                                make_material(t.mod.mat), get_mat(t.mod.trans), get_mat(t.mod.inv_trans),
-                                               glm::vec2(0.0f), glm::vec2(0.0f), glm::vec2(0.0f)));
+                                               glm::vec2(t.vt1[0], t.vt1[1]), glm::vec2(t.vt2[0], t.vt2[1]), glm::vec2(t.vt3[0], t.vt3[1])));
    }
    for (int i = 0; i < d->n_lights; i++)
       s->lights.push_back(new PointLight(get3(d->lights[i].pos), get3(d->lights[i].clr)));
@@ -201,6 +214,12 @@ void ref_prim_normal(void *h, int prim, const float *o, const float *d, float t,
 {
    Ray r(get3(o), get3(d));
    put3(n, by_id((RefScene *)h, prim)->getNormalAt(r, t));
+}
+void ref_prim_uv(void *h, int prim, const float *o, const float *d, float t, float *uv)
+{
+   Ray r(get3(o), get3(d));
+   glm::vec2 v = by_id((RefScene *)h, prim)->UVAt(r, t);
+   uv[0] = v.x; uv[1] = v.y;
 }
 void ref_prim_bbox(void *h, int prim, float *mn, float *mx)
 {

@@ -185,6 +185,7 @@ typedef struct geom {
    /* Triangle / SmoothTriangle */
    v3 p1, p2, p3, tn, tc, wsNormal;
    v3 wsN1, wsN2, wsN3;
+   float vt1[2], vt2[2], vt3[2];
    /* Box */
    v3 minP, maxP;
 } geom;
@@ -416,6 +417,8 @@ struct orc_scene {
    geom *geoms;        /* geomList in creation order: id = index */
    geom *planes;
    rt_light *lights;
+   int n_textures;
+   rt_texture *textures;   /* copies (pixels included) */
    int32_t *order;     /* geomList after the sort rounds */
    bvh_node *nodes;
    int n_nodes;
@@ -595,10 +598,30 @@ orc_scene *orc_scene_create(const rt_scene_desc *desc)
    for (int i = 0; i < desc->n_planes; i++) plane_init(&s->planes[i], &desc->planes[i]);
    int k = 0;
    for (int i = 0; i < desc->n_spheres; i++) sphere_init(&s->geoms[k++], &desc->spheres[i]);
-   for (int i = 0; i < desc->n_triangles; i++)
-      triangle_init(&s->geoms[k++], G_TRIANGLE, desc->triangles[i].p1, desc->triangles[i].p2, desc->triangles[i].p3, &desc->triangles[i].mod);
+   for (int i = 0; i < desc->n_triangles; i++) {
+      const rt_triangle *t = &desc->triangles[i];
+      triangle_init(&s->geoms[k], G_TRIANGLE, t->p1, t->p2, t->p3, &t->mod);
+      memcpy(s->geoms[k].vt1, t->vt1, 8); memcpy(s->geoms[k].vt2, t->vt2, 8); memcpy(s->geoms[k].vt3, t->vt3, 8);
+      k++;
+   }
    for (int i = 0; i < desc->n_boxes; i++) box_init(&s->geoms[k++], &desc->boxes[i]);
-   for (int i = 0; i < desc->n_smooth_triangles; i++) smooth_init(&s->geoms[k++], &desc->smooth_triangles[i]);
+   for (int i = 0; i < desc->n_smooth_triangles; i++) {
+      const rt_smooth_triangle *t = &desc->smooth_triangles[i];
+      smooth_init(&s->geoms[k], t);
+      memcpy(s->geoms[k].vt1, t->vt1, 8); memcpy(s->geoms[k].vt2, t->vt2, 8); memcpy(s->geoms[k].vt3, t->vt3, 8);
+      k++;
+   }
+   s->n_textures = desc->n_textures;
+   s->textures = (rt_texture *)calloc((size_t)(desc->n_textures > 0 ? desc->n_textures : 1), sizeof(rt_texture));
+   for (int i = 0; i < desc->n_textures; i++) {
+      s->textures[i] = desc->textures[i];
+      s->textures[i].rgba = NULL;
+      if (desc->textures[i].rgba) {
+         size_t bytes = (size_t)desc->textures[i].width * (size_t)desc->textures[i].height * 4;
+         s->textures[i].rgba = (uint8_t *)malloc(bytes);
+         memcpy(s->textures[i].rgba, desc->textures[i].rgba, bytes);
+      }
+   }
    for (int i = 0; i < desc->n_lights; i++) s->lights[i] = desc->lights[i];
    formBVH(s);
    return s;
@@ -608,6 +631,7 @@ void orc_scene_destroy(orc_scene *s)
 {
    if (!s) return;
    free(s->geoms); free(s->planes); free(s->lights); free(s->order); free(s->nodes); free(s->trace);
+   if (s->textures) { for (int i = 0; i < s->n_textures; i++) free(s->textures[i].rgba); free(s->textures); }
    free(s);
 }
 
@@ -876,6 +900,55 @@ static v3 getRefraction(const shade_ctx *cx, int invRecLevel, v3 point, v3 norma
    return V(0.0f, 0.0f, 0.0f);
 }
 
+/* Triangle::UVAt, Triangle.h:44-52 (SmoothTriangle inherits it); the other classes return vec2(0)
+ * (Sphere.h:34-37, Plane.h:32-35, Box.h:25-28). */
+static void orc_uv_at(const geom *g, const ray_t *r, float param, float *uv)
+{
+   uv[0] = uv[1] = 0.0f;
+   if (g->type != G_TRIANGLE && g->type != G_SMOOTH) return;
+   v3 q = ray_point(r, param);
+   float area = vdot(vcross(vsub(g->p2, g->p1), vsub(g->p3, g->p1)), g->tn);
+   float beta = vdot(vcross(vsub(g->p1, g->p3), vsub(q, g->p3)), g->tn) / area;
+   float gamma = vdot(vcross(vsub(g->p2, g->p1), vsub(q, g->p1)), g->tn) / area;
+   float alpha = (float)(1.0 - (double)beta - (double)gamma);   /* "1.0" is a double literal */
+   uv[0] = alpha * g->vt1[0] + beta * g->vt2[0] + gamma * g->vt3[0];
+   uv[1] = alpha * g->vt1[1] + beta * g->vt2[1] + gamma * g->vt3[1];
+}
+
+/* tex2D(mytex, u, v) for the texture the reference binds (kernel.cu:32, 590-593): uchar4 texels read as
+ * normalised floats, wrap addressing, linear filtering, normalised coordinates.  Restated from the
+ * published description of CUDA's linear filter: x = frac(u)*W - 0.5, the four texels around it, weights
+ * in 9-bit fixed point with 8 fractional bits.  There is no CUDA texture unit here to check the last
+ * bit against: PARITY UNPINNED for this function (the reference's blitzcrank.tga is the only witness). */
+static void orc_tex2d(const rt_texture *tex, float u, float v, float *rgb)
+{
+   int W = tex->width, H = tex->height;
+   float x = (u - floorf(u)) * (float)W - 0.5f;
+   float y = (v - floorf(v)) * (float)H - 0.5f;
+   float fx = floorf(x), fy = floorf(y);
+   float a = floorf((x - fx) * 256.0f + 0.5f) * 0.00390625f;
+   float b = floorf((y - fy) * 256.0f + 0.5f) * 0.00390625f;
+   int i0 = (int)fx, j0 = (int)fy;
+   i0 = ((i0 % W) + W) % W; j0 = ((j0 % H) + H) % H;
+   int i1 = (i0 + 1) % W, j1 = (j0 + 1) % H;
+   const uint8_t *t00 = tex->rgba + 4 * ((size_t)j0 * W + i0), *t10 = tex->rgba + 4 * ((size_t)j0 * W + i1);
+   const uint8_t *t01 = tex->rgba + 4 * ((size_t)j1 * W + i0), *t11 = tex->rgba + 4 * ((size_t)j1 * W + i1);
+   float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+   for (int c = 0; c < 3; c++)
+      rgb[c] = w00 * ((float)t00[c] / 255.0f) + w10 * ((float)t10[c] / 255.0f) + w01 * ((float)t01[c] / 255.0f) +
+               w11 * ((float)t11[c] / 255.0f);
+}
+
+/* getColor, kernel.cu:323-332 */
+static v3 getColor(const orc_scene *s, const geom *g, const ray_t *ray, float param)
+{
+   if (g->mat.tex_id == -1 || g->mat.tex_id >= s->n_textures || !s->textures[g->mat.tex_id].rgba) return vload(g->mat.clr);
+   float uv[2], rgb[3];
+   orc_uv_at(g, ray, param, uv);
+   orc_tex2d(&s->textures[g->mat.tex_id], uv[0], uv[1], rgb);
+   return V(rgb[0], rgb[1], rgb[2]);
+}
+
 static v3 shadeObject(const shade_ctx *cx, int invRecLevel, int geomId, float intParam, ray_t ray)
 {
    if (invRecLevel == 0) return V(0.0f, 0.0f, 0.0f);
@@ -886,7 +959,7 @@ static v3 shadeObject(const shade_ctx *cx, int invRecLevel, int geomId, float in
    v3 intersectPoint = ray_point(&ray, intParam);
    rt_material m = g->mat;
    v3 normal = geom_getNormalAt(g, &ray, intParam);
-   v3 matClr = vload(m.clr);   /* getColor, kernel.cu:323-332, untextured branch */
+   v3 matClr = getColor(s, g, &ray, intParam);
    v3 eyeVec = vnormalize(vneg(ray.d));
    v3 totalLight = V(0.0f, 0.0f, 0.0f);
 
@@ -1046,6 +1119,12 @@ void orc_prim_normal(const orc_scene *s, int32_t prim, const float o[3], const f
    ray_t r; r.o = vload(o); r.d = vload(d);
    store3(n, geom_getNormalAt(geom_by_id(s, prim), &r, t));
 }
+void orc_prim_uv(const orc_scene *s, int32_t prim, const float o[3], const float d[3], float t, float uv[2])
+{
+   ray_t r; r.o = vload(o); r.d = vload(d);
+   orc_uv_at(geom_by_id(s, prim), &r, t, uv);
+}
+void orc_texture_sample(const rt_texture *tex, float u, float v, float rgb[3]) { orc_tex2d(tex, u, v, rgb); }
 void orc_prim_bbox(const orc_scene *s, int32_t prim, float mn[3], float mx[3])
 {
    bbox_t b = geom_getBoundingBox(geom_by_id(s, prim));

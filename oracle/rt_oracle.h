@@ -73,6 +73,8 @@ void orc_closest(const orc_scene *s, const float o[3], const float d[3], float t
 /* Per-primitive pieces (used to pin this file against the real classes). */
 float orc_prim_intersect(const orc_scene *s, int32_t prim, const float o[3], const float d[3]);  /* Geometry::getIntersection, Geometry.h:16-18 */
 void  orc_prim_normal(const orc_scene *s, int32_t prim, const float o[3], const float d[3], float t, float n[3]); /* getNormalAt */
+void  orc_prim_uv(const orc_scene *s, int32_t prim, const float o[3], const float d[3], float t, float uv[2]);    /* UVAt, Triangle.h:44-52 */
+void  orc_texture_sample(const rt_texture *tex, float u, float v, float rgb[3]);               /* tex2D as bound at kernel.cu:590-593 */
 void  orc_prim_bbox(const orc_scene *s, int32_t prim, float mn[3], float mx[3]);                 /* getBoundingBox */
 void  orc_prim_center(const orc_scene *s, int32_t prim, float c[3]);                             /* getCenter */
 float orc_box_intersect(const float o[3], const float d[3], const float mn[3], const float mx[3]); /* boxIntersect, GeometryUtil.h:9-51 */

@@ -38,22 +38,28 @@ material_dtype = np.dtype([("clr", f32, 3), ("alpha", f32), ("amb", f32), ("dif"
                            ("rough", f32), ("refl", f32), ("refr", f32), ("ior", f32), ("tex_id", i32)])
 modifier_dtype = np.dtype([("mat", material_dtype), ("trans", f32, 16), ("inv_trans", f32, 16)])
 sphere_dtype = np.dtype([("c", f32, 3), ("r", f32), ("mod", modifier_dtype)])
-triangle_dtype = np.dtype([("p1", f32, 3), ("p2", f32, 3), ("p3", f32, 3), ("mod", modifier_dtype)])
+triangle_dtype = np.dtype([("p1", f32, 3), ("p2", f32, 3), ("p3", f32, 3),
+                           ("vt1", f32, 2), ("vt2", f32, 2), ("vt3", f32, 2), ("mod", modifier_dtype)])
 box_dtype = np.dtype([("p1", f32, 3), ("p2", f32, 3), ("mod", modifier_dtype)])
 smooth_triangle_dtype = np.dtype([("p1", f32, 3), ("p2", f32, 3), ("p3", f32, 3),
-                                  ("n1", f32, 3), ("n2", f32, 3), ("n3", f32, 3), ("mod", modifier_dtype)])
+                                  ("n1", f32, 3), ("n2", f32, 3), ("n3", f32, 3),
+                                  ("vt1", f32, 2), ("vt2", f32, 2), ("vt3", f32, 2), ("mod", modifier_dtype)])
 plane_dtype = np.dtype([("n", f32, 3), ("d", f32), ("mod", modifier_dtype)])
 light_dtype = np.dtype([("pos", f32, 3), ("clr", f32, 3)])
 bvh_node_dtype = np.dtype([("lmin", f32, 3), ("lmax", f32, 3), ("rmin", f32, 3), ("rmax", f32, 3),
                            ("left", i32), ("right", i32), ("pad", i32, 2)])
 assert material_dtype.itemsize == 48 and modifier_dtype.itemsize == 176
-assert sphere_dtype.itemsize == 192 and triangle_dtype.itemsize == 212 and box_dtype.itemsize == 200
-assert smooth_triangle_dtype.itemsize == 248 and plane_dtype.itemsize == 192 and light_dtype.itemsize == 24
+assert sphere_dtype.itemsize == 192 and triangle_dtype.itemsize == 236 and box_dtype.itemsize == 200
+assert smooth_triangle_dtype.itemsize == 272 and plane_dtype.itemsize == 192 and light_dtype.itemsize == 24
 assert bvh_node_dtype.itemsize == 64
 
 
 class Camera(C.Structure):
     _fields_ = [("pos", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3), ("look_at", C.c_float * 3)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgba", C.c_void_p), ("name", C.c_char * 128)]
 
 
 class SceneDesc(C.Structure):
@@ -63,7 +69,8 @@ class SceneDesc(C.Structure):
                 ("n_boxes", C.c_int32), ("boxes", C.c_void_p),
                 ("n_smooth_triangles", C.c_int32), ("smooth_triangles", C.c_void_p),
                 ("n_planes", C.c_int32), ("planes", C.c_void_p),
-                ("n_lights", C.c_int32), ("lights", C.c_void_p)]
+                ("n_lights", C.c_int32), ("lights", C.c_void_p),
+                ("n_textures", C.c_int32), ("textures", C.POINTER(Texture))]
 
 
 class RenderParams(C.Structure):
@@ -102,7 +109,7 @@ EXPORTED_SYMBOLS = [
     "rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_create_host", "rt_scene_destroy", "rt_scene_get_info",
     "rt_scene_get_bvh", "rt_scene_set_camera", "rt_render", "rt_render_device", "rt_tile_count",
     "rt_untile_device", "rt_trace_primary", "rt_trace_rays", "rt_render_samples",
-    "rt_parse_pov", "rt_scene_desc_free", "rt_write_tga", "launch_kernel",
+    "rt_parse_pov", "rt_scene_desc_free", "rt_load_bmp", "rt_write_tga", "launch_kernel",
 ]
 
 _lib = None
@@ -140,6 +147,7 @@ def load_library(path=None):
     lib.rt_scene_desc_free.argtypes = [C.POINTER(SceneDesc)]
     lib.rt_scene_desc_free.restype = None
     lib.rt_write_tga.argtypes = [C.c_char_p, C.c_int, C.c_int, vp]
+    lib.rt_load_bmp.argtypes = [C.c_char_p, C.POINTER(Texture)]
     if path is None:
         _lib = lib
     return lib

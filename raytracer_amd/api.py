@@ -44,6 +44,18 @@ def parse_pov(path):
         lib.rt_scene_desc_free(out)
 
 
+def load_bmp(path):
+    """readBMP (kernel.cu:35-61) -> (H, W, 4) uint8 texels, row 0 = bottom row of the picture."""
+    lib = abi.load_library()
+    t = abi.Texture()
+    _check(lib, lib.rt_load_bmp(str(path).encode(), C.byref(t)))
+    try:
+        buf = (C.c_char * (t.width * t.height * 4)).from_address(t.rgba)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(t.height, t.width, 4).copy()
+    finally:
+        C.CDLL(None).free(C.c_void_p(t.rgba))
+
+
 def write_tga(path, rgba):
     """Frame (H, W, 4) uint8, row 0 = bottom row -> TGA as the reference's driver writes it."""
     lib = abi.load_library()

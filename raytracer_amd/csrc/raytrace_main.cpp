@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "raytracer_amd.h"
@@ -50,6 +51,16 @@ int main(int argc, char *argv[])
 
    rt_scene_desc *desc = NULL;
    if (rt_parse_pov(in_file, &desc) != RT_OK) { fprintf(stderr, "%s\n", rt_last_error()); printf("Error parsing file\n"); return EXIT_FAILURE; }
+   /* image_map files: looked up in the working directory (where the reference reads its one texture,
+    * kernel.cu:580), then next to the scene file */
+   for (int i = 0; i < desc->n_textures; i++) {
+      rt_texture *t = &desc->textures[i];
+      if (rt_load_bmp(t->name, t) == RT_OK) continue;
+      std::string dir(in_file);
+      size_t slash = dir.find_last_of('/');
+      std::string alt = (slash == std::string::npos ? std::string() : dir.substr(0, slash + 1)) + t->name;
+      if (rt_load_bmp(alt.c_str(), t) != RT_OK) { fprintf(stderr, "%s\n", rt_last_error()); return EXIT_FAILURE; }
+   }
    rt_scene *scene = NULL;
    if (rt_scene_create(desc, device, RT_SCENE_DEFAULT, &scene) != RT_OK) { fprintf(stderr, "%s\n", rt_last_error()); return EXIT_FAILURE; }
    if (width <= 0 || height <= 0) { fprintf(stderr, "bad image size\n"); return EXIT_FAILURE; }

@@ -41,11 +41,16 @@ typedef struct rt_dev_xform {
  *   sphere   s[0..2] world-space centre                           (Sphere.h:13-14, 19-24)
  *   triangle s[0..2] world-space normal = (n,0) * inv_trans       (Triangle.h:20-26)
  *   smooth   s[0..8] wsN1 wsN2 wsN3                               (SmoothTriangle.h:21-38)
+ *   both triangle kinds keep their six texture coordinates in s[9..11], uv[0..2]
  *   box      s[0..8] columns 0..2 of trans, rows 0..2             (Box.h:59)                    */
 typedef struct rt_dev_shade {
    float s[12];
-   uint32_t pad[4];
+   float uv[3];                  /* triangles: s[9..11], uv[0..2] = vt1, vt2, vt3 (Triangle.h:44-52) */
+   uint32_t pad;
 } rt_dev_shade;
+
+/* One texture of the scene: its texels start at `offset` (in texels) of the texel array. */
+typedef struct rt_dev_texinfo { uint32_t offset; int32_t width, height; uint32_t pad; } rt_dev_texinfo;
 
 /* Plane (not in the BVH; scanned linearly after it, kernel.cu:189-196). */
 typedef struct rt_dev_plane {
@@ -71,6 +76,10 @@ typedef struct rt_flat_scene {
    rt_material *materials;     /* n_materials (deduplicated) */
    rt_dev_light *lights;       /* n_lights */
    int32_t *leaf_order;        /* n_prims: geomList after formBVH's sort rounds */
+   int32_t n_textures;
+   rt_dev_texinfo *tex_info;   /* n_textures */
+   uint8_t *texels;            /* 4 bytes per texel, all textures back to back */
+   size_t n_texels;
    int32_t any_xform;
    int32_t bounds_in_range;    /* every node bound is finite with magnitude <= 2^40 (or zero) */
 } rt_flat_scene;

@@ -23,6 +23,7 @@ static_assert(sizeof(TKSmoothTriangle) == 72 + 24 + sizeof(TKModifier), "TKSmoot
 
 namespace {
 void put3(float *d, const rt_vec3 &v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+void put2(float *d, const rt_vec2 &v) { d[0] = v.x; d[1] = v.y; }
 void put_mod(rt_modifier *d, const TKModifier &m)
 {
    /* Material(clr, pig.f, amb, dif, spec, rough, refl, refr, ior[, texId]): kernel.cu:414, 422, 431, 441, 450 */
@@ -62,6 +63,7 @@ extern "C" void launch_kernel(TKSceneData *data, ShadingType stype, int width, i
    for (size_t i = 0; i < tris.size(); i++) {
       const TKTriangle &t = data->triangles[i];
       put3(tris[i].p1, t.p1); put3(tris[i].p2, t.p2); put3(tris[i].p3, t.p3); put_mod(&tris[i].mod, t.mod);
+      put2(tris[i].vt1, t.vt1); put2(tris[i].vt2, t.vt2); put2(tris[i].vt3, t.vt3);
    }
    for (size_t i = 0; i < boxes.size(); i++) { put3(boxes[i].p1, data->boxes[i].p1); put3(boxes[i].p2, data->boxes[i].p2); put_mod(&boxes[i].mod, data->boxes[i].mod); }
    for (size_t i = 0; i < smooth.size(); i++) {
@@ -69,6 +71,7 @@ extern "C" void launch_kernel(TKSceneData *data, ShadingType stype, int width, i
       put3(smooth[i].p1, t.p1); put3(smooth[i].p2, t.p2); put3(smooth[i].p3, t.p3);
       put3(smooth[i].n1, t.n1); put3(smooth[i].n2, t.n2); put3(smooth[i].n3, t.n3);
       put_mod(&smooth[i].mod, t.mod);
+      put2(smooth[i].vt1, t.vt1); put2(smooth[i].vt2, t.vt2); put2(smooth[i].vt3, t.vt3);
    }
    for (size_t i = 0; i < planes.size(); i++) { put3(planes[i].n, data->planes[i].n); planes[i].d = data->planes[i].d; put_mod(&planes[i].mod, data->planes[i].mod); }
    for (size_t i = 0; i < lights.size(); i++) { put3(lights[i].pos, data->pointLights[i].pos); put3(lights[i].clr, data->pointLights[i].clr); }
@@ -84,10 +87,20 @@ extern "C" void launch_kernel(TKSceneData *data, ShadingType stype, int width, i
    d.n_planes = (int32_t)planes.size(); d.planes = planes.data();
    d.n_lights = (int32_t)lights.size(); d.lights = lights.data();
 
+   /* Textures: the reference reads "blitz.bmp" from the working directory and binds it to every textured
+    * primitive, whatever name the scene gave (kernel.cu:580-598).  Same here, but only when a texture is used. */
+   std::vector<rt_texture> textures(data->textureMap.size());
+   rt_texture blitz; memset(&blitz, 0, sizeof blitz);
+   if (!textures.empty()) {
+      if (rt_load_bmp("blitz.bmp", &blitz) != RT_OK) die("texture load failed");
+      for (size_t i = 0; i < textures.size(); i++) { textures[i] = blitz; snprintf(textures[i].name, sizeof textures[i].name, "blitz.bmp"); }
+   }
+   d.n_textures = (int32_t)textures.size(); d.textures = textures.empty() ? NULL : textures.data();
+
    const char *dev_env = getenv("RT_DEVICE");
    const char *jit_env = getenv("RT_JITTER");
    rt_scene *scene = NULL;
-   if (rt_scene_create(&d, dev_env ? atoi(dev_env) : 0, RT_SCENE_DEFAULT, &scene) != RT_OK) die("scene set-up failed");
+   if (rt_scene_create(&d, dev_env ? atoi(dev_env) : 0, RT_SCENE_DEFAULT, &scene) != RT_OK) { free(blitz.rgba); die("scene set-up failed"); }
    rt_render_params p; memset(&p, 0, sizeof p);
    p.width = width; p.height = height; p.sample_count = sampleCount;
    p.shading = stype == COOK_TORRANCE ? RT_COOK_TORRANCE : RT_PHONG;
@@ -95,5 +108,6 @@ extern "C" void launch_kernel(TKSceneData *data, ShadingType stype, int width, i
    p.seed = 0; p.max_recurse = RT_MAX_RECURSE; p.tile_first = 0; p.tile_stride = 1; p.out_layout = RT_OUT_FRAME;
    int rc = rt_render(scene, &p, (uint8_t *)output, NULL);
    rt_scene_destroy(scene);
+   free(blitz.rgba);
    if (rc != RT_OK) die("RayTrace kernel failed");
 }

@@ -263,12 +263,12 @@ bool parse_vector(Scanner &in, float *v)
    if (sscanf(buf.c_str(), " < %f , %f , %f > ", &v[0], &v[1], &v[2]) == 3) return true;
    return fail("Bad format for vector entry");
 }
-/* parseUV, POVRayParser.cpp:630-643 (values are not kept: textures are out of scope) */
-bool parse_uv(Scanner &in)
+/* parseUV, POVRayParser.cpp:630-643 */
+bool parse_uv(Scanner &in, float *uv)
 {
    std::string buf; float a, b;
    in.getline(buf, '>');
-   if (sscanf(buf.c_str(), " < %f , %f > ", &a, &b) == 2) return true;
+   if (sscanf(buf.c_str(), " < %f , %f > ", &a, &b) == 2) { uv[0] = a; uv[1] = b; return true; }
    return fail("Bad format for uv entry");
 }
 bool parse_word(Scanner &in, const char *s)
@@ -364,13 +364,13 @@ bool parse_modifiers(Scanner &in, rt_modifier *mod, SceneOut &out)
    return true;
 }
 
-bool maybe_uv(Scanner &in)
+bool maybe_uv(Scanner &in, float *vt1, float *vt2, float *vt3)
 {
    if (in.at_end()) return true;
    std::string w = in.peek_word();
    if (w.size() >= 2 && w[0] == 'u' && w[1] == 'v') {
-      return parse_word(in, "uv") && parse_char(in, '{') && parse_uv(in) && parse_char(in, ',') && parse_uv(in) &&
-             parse_char(in, ',') && parse_uv(in) && parse_char(in, '}');
+      return parse_word(in, "uv") && parse_char(in, '{') && parse_uv(in, vt1) && parse_char(in, ',') && parse_uv(in, vt2) &&
+             parse_char(in, ',') && parse_uv(in, vt3) && parse_char(in, '}');
    }
    return true;
 }
@@ -458,19 +458,19 @@ bool parse_file(Scanner &in, SceneOut &out)
          if (!ok) return false;
       } else if (first == "triangle") {
          /* POVRayParser.cpp:374-430 */
-         rt_triangle t; default_modifier(&t.mod);
+         rt_triangle t; memset(&t, 0, sizeof t); default_modifier(&t.mod);
          if (!parse_char(in, '{') || !parse_vector(in, t.p1) || !parse_char(in, ',') || !parse_vector(in, t.p2) ||
-             !parse_char(in, ',') || !parse_vector(in, t.p3) || !maybe_uv(in)) return false;
+             !parse_char(in, ',') || !parse_vector(in, t.p3) || !maybe_uv(in, t.vt1, t.vt2, t.vt3)) return false;
          bool ok = parse_modifiers(in, &t.mod, out);
          out.triangles.push_back(t);
          if (!ok) return false;
       } else if (first == "smooth_triangle") {
          /* POVRayParser.cpp:301-373: point, normal, point, normal, point, normal */
-         rt_smooth_triangle t; default_modifier(&t.mod);
+         rt_smooth_triangle t; memset(&t, 0, sizeof t); default_modifier(&t.mod);
          if (!parse_char(in, '{') || !parse_vector(in, t.p1) || !parse_char(in, ',') || !parse_vector(in, t.n1) ||
              !parse_char(in, ',') || !parse_vector(in, t.p2) || !parse_char(in, ',') || !parse_vector(in, t.n2) ||
              !parse_char(in, ',') || !parse_vector(in, t.p3) || !parse_char(in, ',') || !parse_vector(in, t.n3) ||
-             !maybe_uv(in)) return false;
+             !maybe_uv(in, t.vt1, t.vt2, t.vt3)) return false;
          bool ok = parse_modifiers(in, &t.mod, out);
          out.smooth.push_back(t);
          if (!ok) return false;
@@ -514,7 +514,40 @@ extern "C" int rt_parse_pov(const char *path, rt_scene_desc **out)
    d->n_smooth_triangles = (int32_t)so.smooth.size(); d->smooth_triangles = release(so.smooth);
    d->n_planes = (int32_t)so.planes.size(); d->planes = release(so.planes);
    d->n_lights = (int32_t)so.lights.size(); d->lights = release(so.lights);
+   d->n_textures = (int32_t)so.textures.size();
+   d->textures = (rt_texture *)calloc(so.textures.size() ? so.textures.size() : 1, sizeof(rt_texture));
+   for (std::map<std::string, int>::const_iterator it = so.textures.begin(); it != so.textures.end(); ++it) {
+      rt_texture &t = d->textures[it->second];
+      /* the reference's sscanf("%s") keeps the closing quote in the name (POVRayParser.cpp:493); it is dropped here */
+      std::string name = it->first;
+      while (!name.empty() && (name[name.size() - 1] == '"' || name[name.size() - 1] == '}')) name.erase(name.size() - 1);
+      snprintf(t.name, sizeof t.name, "%s", name.c_str());
+   }
    *out = d;
+   return RT_OK;
+}
+
+extern "C" int rt_load_bmp(const char *path, rt_texture *tex)
+{
+   if (!path || !tex) { rt_set_error("rt_load_bmp: null argument"); return RT_ERR_BAD_ARGUMENT; }
+   FILE *f = fopen(path, "rb");
+   if (!f) { rt_set_error("texture \"%s\" not found", path); return RT_ERR_IO; }
+   unsigned char info[54];
+   if (fread(info, 1, 54, f) != 54 || info[0] != 'B' || info[1] != 'M') { fclose(f); rt_set_error("%s is not a .bmp", path); return RT_ERR_PARSE; }
+   int width, height;
+   memcpy(&width, info + 18, 4); memcpy(&height, info + 22, 4);       /* kernel.cu:43-44 */
+   int bits = info[28] | (info[29] << 8);
+   if (width <= 0 || height <= 0 || width > 16384 || height > 16384 || bits != 24) { fclose(f); rt_set_error("%s: only 24-bit bottom-up images are supported", path); return RT_ERR_UNSUPPORTED; }
+   size_t n = (size_t)width * (size_t)height;
+   std::vector<unsigned char> data(3 * n);
+   if (fread(data.data(), 1, 3 * n, f) != 3 * n) { fclose(f); rt_set_error("%s is truncated", path); return RT_ERR_PARSE; }
+   fclose(f);
+   uint8_t *out = (uint8_t *)malloc(4 * n);
+   for (size_t i = 0; i < n; i++) {                                    /* kernel.cu:53-59: BGR -> RGB0, rows as stored */
+      out[4 * i] = data[3 * i + 2]; out[4 * i + 1] = data[3 * i + 1]; out[4 * i + 2] = data[3 * i]; out[4 * i + 3] = 0;
+   }
+   free(tex->rgba);
+   tex->width = width; tex->height = height; tex->rgba = out;
    return RT_OK;
 }
 
@@ -523,5 +556,6 @@ extern "C" void rt_scene_desc_free(rt_scene_desc *d)
    if (!d) return;
    free((void *)d->spheres); free((void *)d->triangles); free((void *)d->boxes);
    free((void *)d->smooth_triangles); free((void *)d->planes); free((void *)d->lights);
+   if (d->textures) { for (int i = 0; i < d->n_textures; i++) free(d->textures[i].rgba); free(d->textures); }
    free(d);
 }

@@ -57,6 +57,8 @@ struct DScene {
    const rt_dev_plane *planes;
    const rt_material *materials;
    const rt_dev_light *lights;
+   const rt_dev_texinfo *tex_info;
+   const uchar4 *texels;
    int n_prims, n_planes, n_lights, root;
    int fast_ok;      /* every BVH bound is finite and below 2^40 in magnitude */
 };
@@ -797,6 +799,56 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
 /* kernels                                                                  */
 /* ======================================================================= */
 
+/* tex2D on the texture the reference binds (kernel.cu:32, 590-593): uchar4 texels read as normalised floats, wrap
+ * addressing, linear filtering, normalised coordinates -- x = frac(u)*W - 0.5, the four texels around it, weights
+ * in 9-bit fixed point with 8 fractional bits, as CUDA documents its linear filter. */
+__device__ __forceinline__ F3 texture_sample(const uchar4 *texels, rt_dev_texinfo ti, float u, float v)
+{
+   int W = ti.width, H = ti.height;
+   float x = (u - floorf(u)) * (float)W - 0.5f;
+   float y = (v - floorf(v)) * (float)H - 0.5f;
+   float fx = floorf(x), fy = floorf(y);
+   float a = floorf((x - fx) * 256.0f + 0.5f) * 0.00390625f;
+   float b = floorf((y - fy) * 256.0f + 0.5f) * 0.00390625f;
+   int i0 = (int)fx, j0 = (int)fy;
+   i0 = ((i0 % W) + W) % W; j0 = ((j0 % H) + H) % H;
+   int i1 = (i0 + 1) % W, j1 = (j0 + 1) % H;
+   const uchar4 *base = texels + ti.offset;
+   uchar4 t00 = base[(size_t)j0 * W + i0], t10 = base[(size_t)j0 * W + i1];
+   uchar4 t01 = base[(size_t)j1 * W + i0], t11 = base[(size_t)j1 * W + i1];
+   float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+   F3 c;
+   c.x = w00 * ((float)t00.x / 255.0f) + w10 * ((float)t10.x / 255.0f) + w01 * ((float)t01.x / 255.0f) + w11 * ((float)t11.x / 255.0f);
+   c.y = w00 * ((float)t00.y / 255.0f) + w10 * ((float)t10.y / 255.0f) + w01 * ((float)t01.y / 255.0f) + w11 * ((float)t11.y / 255.0f);
+   c.z = w00 * ((float)t00.z / 255.0f) + w10 * ((float)t10.z / 255.0f) + w01 * ((float)t01.z / 255.0f) + w11 * ((float)t11.z / 255.0f);
+   return c;
+}
+
+/* getColor, kernel.cu:323-332: the pigment colour, or the texture at UVAt (Triangle.h:44-52; the other classes
+ * return vec2(0): Sphere.h:34-37, Plane.h:32-35, Box.h:25-28) */
+__device__ __forceinline__ F3 material_color(const DScene &sc, const rt_material &m, int prim, const Ray &ray, float t)
+{
+   if (m.tex_id == -1) return mk3(m.clr[0], m.clr[1], m.clr[2]);
+   float u = 0.0f, v = 0.0f;
+   if (prim < sc.n_prims) {
+      PrimRec p = load_prim(sc.prims, prim);
+      if (p.m.x == RT_PRIM_TRIANGLE || p.m.x == RT_PRIM_SMOOTH) {
+         const float4 *sp = reinterpret_cast<const float4 *>(sc.shades + prim);
+         float4 s2 = sp[2], s3 = sp[3];
+         F3 p1 = mk3(p.a.x, p.a.y, p.a.z), p2 = mk3(p.a.w, p.b.x, p.b.y), p3 = mk3(p.b.z, p.b.w, p.c.x);
+         F3 n = mk3(p.c.y, p.c.z, p.c.w);
+         F3 q = ray_point(ray, t);
+         float area = dot3(cross3(p2 - p1, p3 - p1), n);
+         float beta = dot3(cross3(p1 - p3, q - p3), n) / area;
+         float gamma = dot3(cross3(p2 - p1, q - p1), n) / area;
+         float alpha = (float)(1.0 - (double)beta - (double)gamma);   /* the reference's "1.0" is a double */
+         u = alpha * s2.y + beta * s2.w + gamma * s3.y;                /* vt1 = s[9..10], vt2 = s[11], uv[0], vt3 = uv[1..2] */
+         v = alpha * s2.z + beta * s3.x + gamma * s3.z;
+      }
+   }
+   return texture_sample(sc.texels, sc.tex_info[m.tex_id], u, v);
+}
+
 /* PhongShader::shade, PhongShader.h:7-25 */
 __device__ __forceinline__ F3 phong(F3 matColor, float amb, float dif, float spec, float rough, F3 eye, F3 lightDir,
                                     F3 lightColor, F3 normal, bool inShadow)
@@ -868,7 +920,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue
    F3 total = mk3(0.0f, 0.0f, 0.0f);
    if (h.prim >= 0) {
       ShadePoint sp = shade_point(sc, queue, i, h);
-      F3 matClr = mk3(sp.m.clr[0], sp.m.clr[1], sp.m.clr[2]);      /* getColor, untextured (kernel.cu:323-326) */
+      F3 matClr = material_color(sc, sp.m, h.prim, sp.ray, h.t);
       for (int l = 0; l < sc.n_lights; l++) {
          const rt_dev_light &L = sc.lights[l];
          F3 lc = mk3(L.clr[0], L.clr[1], L.clr[2]);
@@ -1107,18 +1159,19 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->ms_build_host = std::chrono::duration<float, std::milli>(t1 - t0).count();
 
    const rt_flat_scene &h = s->host;
-   size_t off[8], sizes[7] = {
+   enum { N_ARR = 9 };
+   size_t off[N_ARR + 1], sizes[N_ARR] = {
       sizeof(rt_bvh_node) * (size_t)h.n_nodes, sizeof(rt_dev_prim) * (size_t)h.n_prims,
       sizeof(rt_dev_xform) * (size_t)h.n_prims, sizeof(rt_dev_shade) * (size_t)h.n_prims,
       sizeof(rt_dev_plane) * (size_t)h.n_planes, sizeof(rt_material) * (size_t)h.n_materials,
-      sizeof(rt_dev_light) * (size_t)h.n_lights};
+      sizeof(rt_dev_light) * (size_t)h.n_lights, sizeof(rt_dev_texinfo) * (size_t)h.n_textures, 4 * h.n_texels};
    off[0] = 0;
-   for (int k = 0; k < 7; k++) off[k + 1] = off[k] + align_up(sizes[k] ? sizes[k] : 64, 256);
-   s->dev_bytes = off[7];
+   for (int k = 0; k < N_ARR; k++) off[k + 1] = off[k] + align_up(sizes[k] ? sizes[k] : 64, 256);
+   s->dev_bytes = off[N_ARR];
    hipError_t e = hipMalloc(&s->dev_blob, s->dev_bytes);
    if (e != hipSuccess) { rt_set_error("hipMalloc(%zu) failed: %s", s->dev_bytes, hipGetErrorString(e)); rt_scene_destroy(s); return RT_ERR_HIP; }
-   const void *src[7] = {h.nodes, h.prims, h.xforms, h.shades, h.planes, h.materials, h.lights};
-   for (int k = 0; k < 7; k++) {
+   const void *src[N_ARR] = {h.nodes, h.prims, h.xforms, h.shades, h.planes, h.materials, h.lights, h.tex_info, h.texels};
+   for (int k = 0; k < N_ARR; k++) {
       if (!sizes[k]) continue;
       e = hipMemcpy((char *)s->dev_blob + off[k], src[k], sizes[k], hipMemcpyHostToDevice);
       if (e != hipSuccess) { rt_set_error("scene upload failed: %s", hipGetErrorString(e)); rt_scene_destroy(s); return RT_ERR_HIP; }
@@ -1128,6 +1181,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->d.xforms = (const rt_dev_xform *)(b + off[2]); s->d.shades = (const rt_dev_shade *)(b + off[3]);
    s->d.planes = (const rt_dev_plane *)(b + off[4]); s->d.materials = (const rt_material *)(b + off[5]);
    s->d.lights = (const rt_dev_light *)(b + off[6]);
+   s->d.tex_info = (const rt_dev_texinfo *)(b + off[7]); s->d.texels = (const uchar4 *)(b + off[8]);
    s->d.n_prims = h.n_prims; s->d.n_planes = h.n_planes; s->d.n_lights = h.n_lights; s->d.root = h.root;
    s->d.fast_ok = h.bounds_in_range;
 

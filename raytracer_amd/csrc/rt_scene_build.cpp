@@ -153,7 +153,7 @@ struct Builder {
 
    /* Triangle.h:11-42; SmoothTriangle.h:12-28 */
    void add_triangle(const float *a, const float *b, const float *c, const rt_modifier &mod,
-                     const float *n1, const float *n2, const float *n3)
+                     const float *n1, const float *n2, const float *n3, const float *vt1, const float *vt2, const float *vt3)
    {
       rt_dev_prim p; common(p, n1 ? RT_PRIM_SMOOTH : RT_PRIM_TRIANGLE, mod);
       F3 p1 = f3(a), p2 = f3(b), p3 = f3(c);
@@ -167,6 +167,7 @@ struct Builder {
       } else {
          put(&sh.s[0], vec_mat(n.x, n.y, n.z, 0.0f, mod.inv_trans));
       }
+      sh.s[9] = vt1[0]; sh.s[10] = vt1[1]; sh.s[11] = vt2[0]; sh.uv[0] = vt2[1]; sh.uv[1] = vt3[0]; sh.uv[2] = vt3[1];
       prims.push_back(p); shades.push_back(sh);
       /* sort key: centroid as a ROW vector times trans -- the translation column never enters (Triangle.h:28-31) */
       F3 s3 = (p1 + p2) + p3;
@@ -354,6 +355,18 @@ struct SahBuilder {
    }
 };
 
+/* a material's texture reference must name a texture whose pixels are there */
+bool tex_ok(const rt_scene_desc *d, int tex_id)
+{
+   if (tex_id == -1) return true;
+   if (tex_id < 0 || tex_id >= d->n_textures || !d->textures || !d->textures[tex_id].rgba ||
+       d->textures[tex_id].width <= 0 || d->textures[tex_id].height <= 0) {
+      rt_set_error("material refers to texture %d, which is not loaded (rt_load_bmp)", tex_id);
+      return false;
+   }
+   return true;
+}
+
 template <class T> T *copy_out(const std::vector<T> &v)
 {
    T *p = (T *)malloc(sizeof(T) * (v.size() ? v.size() : 1));
@@ -397,7 +410,7 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
    std::vector<rt_dev_plane> planes((size_t)d->n_planes);
    for (int i = 0; i < d->n_planes; i++) {
       const rt_plane &p = d->planes[i];
-      if (p.mod.mat.tex_id != -1) { rt_set_error("plane %d: textured pigments are not supported", i); return RT_ERR_UNSUPPORTED; }
+      if (!tex_ok(d, p.mod.mat.tex_id)) return RT_ERR_BAD_ARGUMENT;
       rt_dev_plane &o = planes[(size_t)i];
       memset(&o, 0, sizeof o);
       o.n[0] = p.n[0]; o.n[1] = p.n[1]; o.n[2] = p.n[2]; o.d = p.d;
@@ -408,22 +421,22 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
    }
    /* geomList order: spheres, triangles, boxes, smooth triangles (kernel.cu:419-456) */
    for (int i = 0; i < d->n_spheres; i++) {
-      if (d->spheres[i].mod.mat.tex_id != -1) { rt_set_error("sphere %d: textured pigments are not supported", i); return RT_ERR_UNSUPPORTED; }
+      if (!tex_ok(d, d->spheres[i].mod.mat.tex_id)) return RT_ERR_BAD_ARGUMENT;
       b.add_sphere(d->spheres[i]);
    }
    for (int i = 0; i < d->n_triangles; i++) {
       const rt_triangle &t = d->triangles[i];
-      if (t.mod.mat.tex_id != -1) { rt_set_error("triangle %d: textured pigments are not supported", i); return RT_ERR_UNSUPPORTED; }
-      b.add_triangle(t.p1, t.p2, t.p3, t.mod, NULL, NULL, NULL);
+      if (!tex_ok(d, t.mod.mat.tex_id)) return RT_ERR_BAD_ARGUMENT;
+      b.add_triangle(t.p1, t.p2, t.p3, t.mod, NULL, NULL, NULL, t.vt1, t.vt2, t.vt3);
    }
    for (int i = 0; i < d->n_boxes; i++) {
-      if (d->boxes[i].mod.mat.tex_id != -1) { rt_set_error("box %d: textured pigments are not supported", i); return RT_ERR_UNSUPPORTED; }
+      if (!tex_ok(d, d->boxes[i].mod.mat.tex_id)) return RT_ERR_BAD_ARGUMENT;
       b.add_box(d->boxes[i]);
    }
    for (int i = 0; i < d->n_smooth_triangles; i++) {
       const rt_smooth_triangle &t = d->smooth_triangles[i];
-      if (t.mod.mat.tex_id != -1) { rt_set_error("smooth_triangle %d: textured pigments are not supported", i); return RT_ERR_UNSUPPORTED; }
-      b.add_triangle(t.p1, t.p2, t.p3, t.mod, t.n1, t.n2, t.n3);
+      if (!tex_ok(d, t.mod.mat.tex_id)) return RT_ERR_BAD_ARGUMENT;
+      b.add_triangle(t.p1, t.p2, t.p3, t.mod, t.n1, t.n2, t.n3, t.vt1, t.vt2, t.vt3);
    }
 
    int n = (int)total;
@@ -525,6 +538,22 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
    out->lights = copy_out(lights);
    order.resize((size_t)n);
    out->leaf_order = copy_out(order);
+   {
+      std::vector<rt_dev_texinfo> info((size_t)d->n_textures);
+      std::vector<uint8_t> texels;
+      for (int i = 0; i < d->n_textures; i++) {
+         const rt_texture &t = d->textures[i];
+         memset(&info[(size_t)i], 0, sizeof(rt_dev_texinfo));
+         if (!t.rgba || t.width <= 0 || t.height <= 0) continue;      /* named but never referenced */
+         info[(size_t)i].offset = (uint32_t)(texels.size() / 4);
+         info[(size_t)i].width = t.width; info[(size_t)i].height = t.height;
+         texels.insert(texels.end(), t.rgba, t.rgba + (size_t)t.width * (size_t)t.height * 4);
+      }
+      out->n_textures = d->n_textures;
+      out->tex_info = copy_out(info);
+      out->texels = copy_out(texels);
+      out->n_texels = texels.size() / 4;
+   }
    return RT_OK;
 }
 
@@ -532,6 +561,6 @@ extern "C" void rt_flat_scene_free(rt_flat_scene *fs)
 {
    if (!fs) return;
    free(fs->nodes); free(fs->prims); free(fs->xforms); free(fs->shades); free(fs->planes);
-   free(fs->materials); free(fs->lights); free(fs->leaf_order);
+   free(fs->materials); free(fs->lights); free(fs->leaf_order); free(fs->tex_info); free(fs->texels);
    memset(fs, 0, sizeof *fs);
 }

@@ -37,6 +37,9 @@ class SceneData:
         self.camera = None  # dict(pos, up, right, look_at) of 3-float sequences
         for name, dt in _ARRAYS:
             setattr(self, name, np.zeros(0, dtype=dt))
+        # image_map textures, indexed by material tex_id: {"name": str, "rgba": (H, W, 4) uint8 or None}; row 0 is
+        # the bottom row of the picture (the order a .bmp stores it)
+        self.textures = []
 
     # ------------------------------------------------------------------ C view
     def to_desc(self):
@@ -53,6 +56,18 @@ class SceneData:
             keep.append(arr)
             setattr(d, "n_" + name, int(arr.shape[0]))
             setattr(d, name, arr.ctypes.data if arr.shape[0] else None)
+        if self.textures:
+            tex = (abi.Texture * len(self.textures))()
+            for i, t in enumerate(self.textures):
+                tex[i].name = t["name"].encode()[:127]
+                if t.get("rgba") is not None:
+                    px = np.ascontiguousarray(t["rgba"], dtype=np.uint8)
+                    keep.append(px)
+                    tex[i].height, tex[i].width = px.shape[0], px.shape[1]
+                    tex[i].rgba = px.ctypes.data
+            keep.append(tex)
+            d.n_textures = len(self.textures)
+            d.textures = C.cast(tex, C.POINTER(abi.Texture))
         return d, keep
 
     @classmethod
@@ -68,6 +83,13 @@ class SceneData:
             if n and ptr:
                 buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
                 setattr(s, name, np.frombuffer(buf, dtype=dt, count=n).copy())
+        for i in range(desc.n_textures):
+            t = desc.textures[i]
+            px = None
+            if t.rgba:
+                buf = (C.c_char * (t.width * t.height * 4)).from_address(t.rgba)
+                px = np.frombuffer(buf, dtype=np.uint8).reshape(t.height, t.width, 4).copy()
+            s.textures.append({"name": t.name.decode(errors="replace"), "rgba": px})
         return s
 
     # ------------------------------------------------------------ persistence
@@ -76,8 +98,12 @@ class SceneData:
         if self.camera is not None:
             cam = np.concatenate([np.asarray(self.camera[k], dtype=np.float32)
                                   for k in ("pos", "up", "right", "look_at")])
+        extra = {"texture_names": np.array([t["name"] for t in self.textures], dtype="U128")}
+        for i, t in enumerate(self.textures):
+            if t.get("rgba") is not None:
+                extra[f"texture_{i}"] = np.ascontiguousarray(t["rgba"], dtype=np.uint8)
         np.savez_compressed(path, camera=cam, has_camera=np.int32(self.camera is not None),
-                            **{name: getattr(self, name) for name, _ in _ARRAYS})
+                            **{name: getattr(self, name) for name, _ in _ARRAYS}, **extra)
 
     @classmethod
     def load(cls, path):
@@ -88,6 +114,9 @@ class SceneData:
             s.camera = {"pos": c[0:3], "up": c[3:6], "right": c[6:9], "look_at": c[9:12]}
         for name, dt in _ARRAYS:
             setattr(s, name, z[name].astype(dt, copy=False))
+        if "texture_names" in z.files:
+            for i, nm in enumerate(z["texture_names"].tolist()):
+                s.textures.append({"name": str(nm), "rgba": z[f"texture_{i}"] if f"texture_{i}" in z.files else None})
         return s
 
     def counts(self):
@@ -104,4 +133,6 @@ class SceneData:
             for k in ("pos", "up", "right", "look_at"):
                 if np.asarray(self.camera[k], np.float32).tobytes() != np.asarray(other.camera[k], np.float32).tobytes():
                     return False
+        if [t["name"] for t in self.textures] != [t["name"] for t in other.textures]:
+            return False
         return all(getattr(self, n).tobytes() == getattr(other, n).tobytes() for n, _ in _ARRAYS)

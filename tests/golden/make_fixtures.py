@@ -31,7 +31,7 @@ from raytracer_amd import abi  # noqa: E402
 REF = orclib.REFERENCE_DIR
 SCENES = ["simple", "simple_reflect", "simple_reflect2", "simple_refract", "simple_spec", "simple_tri", "simple_cam",
           "recurse_simp", "recurse_simp2", "transforms", "box", "final1", "final2", "cornell", "valentine",
-          "ugly_part", "evil", "bunny_small_tris", "bunny", "dragon_large_tris", "balls2", "iceBot"]
+          "ugly_part", "evil", "bunny_small_tris", "bunny", "dragon_large_tris", "balls2", "iceBot", "blitzcrank"]
 TGAS = ["recurse_simp2", "valentine", "final1", "simple_refract", "bunny", "dragon_large_tris", "balls2"]
 fp = orclib.fp
 
@@ -43,10 +43,23 @@ def read_tga(path):
     return np.ascontiguousarray(bgr[:, :, ::-1])      # rows bottom->top as stored, RGB
 
 
+def read_bmp(path):
+    """24-bit bottom-up .bmp -> (H, W, 4) uint8 (r, g, b, 0), rows in file order: what readBMP makes of it (kernel.cu:35-61)."""
+    b = open(path, "rb").read()
+    w, h = int.from_bytes(b[18:22], "little", signed=True), int.from_bytes(b[22:26], "little", signed=True)
+    bgr = np.frombuffer(b, np.uint8, w * h * 3, 54).reshape(h, w, 3)
+    out = np.zeros((h, w, 4), np.uint8)
+    out[:, :, :3] = bgr[:, :, ::-1]
+    return out
+
+
 def main():
     manifest = {"scenes": {}, "tga": {}, "pov": {}}
     for name in SCENES:
         sd = orclib.ref_parse(os.path.join(REF, name + ".pov"))
+        for t in sd.textures:
+            # the reference binds blitz.bmp to every texture id, whatever the name (kernel.cu:580-598)
+            t["rgba"] = read_bmp(os.path.join(REF, "blitz.bmp"))
         sd.save(os.path.join(HERE, "scenes", name + ".npz"))
         manifest["scenes"][name] = sd.counts()
     for name in TGAS:
@@ -67,7 +80,7 @@ def main():
     # known answers of the reference's classes on seeded inputs
     rng = np.random.default_rng(20261111)
     out = {}
-    for name in ["transforms", "box", "cornell", "bunny_small_tris", "iceBot", "balls2"]:
+    for name in ["transforms", "box", "cornell", "bunny_small_tris", "iceBot", "balls2", "blitzcrank"]:
         sd = orclib.ref_parse(os.path.join(REF, name + ".pov"))
         desc, keep = sd.to_desc()
         rs = orclib.ref().ref_scene_create(C.byref(desc))
@@ -77,6 +90,7 @@ def main():
         rays = np.zeros((len(prims), 8, 6), np.float32)
         ts = np.zeros((len(prims), 8), np.float32)
         nrm = np.zeros((len(prims), 8, 3), np.float32)
+        uvs = np.zeros((len(prims), 8, 2), np.float32)
         bbox = np.zeros((len(prims), 6), np.float32)
         cen = np.zeros((len(prims), 3), np.float32)
         for i, p in enumerate(prims):
@@ -94,11 +108,15 @@ def main():
                 t = orclib.ref().ref_prim_intersect(rs, p, o.ctypes.data_as(fp), d.ctypes.data_as(fp))
                 ts[i, k] = t
                 n = np.zeros(3, np.float32)
+                uv = np.zeros(2, np.float32)
                 if t > 0:
                     orclib.ref().ref_prim_normal(rs, p, o.ctypes.data_as(fp), d.ctypes.data_as(fp), C.c_float(t), n.ctypes.data_as(fp))
+                    if name == "blitzcrank" and p >= len(sd.spheres) and p < sd.n_bvh_prims:   # the other classes print and return 0
+                        orclib.ref().ref_prim_uv(rs, p, o.ctypes.data_as(fp), d.ctypes.data_as(fp), C.c_float(t), uv.ctypes.data_as(fp))
                 nrm[i, k] = n
+                uvs[i, k] = uv
         orclib.ref().ref_scene_destroy(rs)
-        out.update({f"{name}_prims": prims, f"{name}_rays": rays, f"{name}_t": ts, f"{name}_normal": nrm,
+        out.update({f"{name}_prims": prims, f"{name}_rays": rays, f"{name}_t": ts, f"{name}_normal": nrm, f"{name}_uv": uvs,
                     f"{name}_bbox": bbox, f"{name}_center": cen})
     # shaders
     n = 512

@@ -70,6 +70,8 @@ def orc():
         lib.orc_prim_intersect.argtypes = [vp, C.c_int32, fp, fp]
         lib.orc_prim_intersect.restype = C.c_float
         lib.orc_prim_normal.argtypes = [vp, C.c_int32, fp, fp, C.c_float, fp]
+        lib.orc_prim_uv.argtypes = [vp, C.c_int32, fp, fp, C.c_float, fp]
+        lib.orc_texture_sample.argtypes = [C.POINTER(abi.Texture), C.c_float, C.c_float, fp]
         lib.orc_prim_bbox.argtypes = [vp, C.c_int32, fp, fp]
         lib.orc_prim_center.argtypes = [vp, C.c_int32, fp]
         lib.orc_box_intersect.argtypes = [fp, fp, fp, fp]
@@ -99,6 +101,7 @@ def ref():
         lib.ref_prim_intersect.argtypes = [vp, C.c_int, fp, fp]
         lib.ref_prim_intersect.restype = C.c_float
         lib.ref_prim_normal.argtypes = [vp, C.c_int, fp, fp, C.c_float, fp]
+        lib.ref_prim_uv.argtypes = [vp, C.c_int, fp, fp, C.c_float, fp]
         lib.ref_prim_bbox.argtypes = [vp, C.c_int, fp, fp]
         lib.ref_prim_center.argtypes = [vp, C.c_int, fp]
         lib.ref_box_intersect.argtypes = [fp, fp, fp, fp]

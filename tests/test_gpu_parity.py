@@ -160,3 +160,40 @@ def test_depth_limit():
             rgb, st = sc.render_samples(96, 72, max_recurse=depth)
         assert np.abs(rgb - ref["rgb"]).max() <= RGB_TOL
         assert st["shade_nodes"] == ref["counters"]["shade_nodes"]
+
+
+def test_camera_update_without_rebuild():
+    """A resident scene rendered from a second camera equals a scene built with that camera (no BVH rebuild)."""
+    sd = load("cornell")
+    cam2 = {"pos": sd.camera["pos"] + np.array([0.7, 0.3, -0.5], np.float32), "up": sd.camera["up"],
+            "right": sd.camera["right"], "look_at": sd.camera["look_at"]}
+    sd2 = load("cornell")
+    sd2.camera = cam2
+    with ra.Scene(sd) as sc:
+        first, _ = sc.render(160, 120, 1, abi.RT_PHONG, abi.RT_JITTER_NONE)
+        sc.set_camera(cam2["pos"], cam2["up"], cam2["right"], cam2["look_at"])
+        moved, _ = sc.render(160, 120, 1, abi.RT_PHONG, abi.RT_JITTER_NONE)
+    with ra.Scene(sd2) as sc:
+        want, _ = sc.render(160, 120, 1, abi.RT_PHONG, abi.RT_JITTER_NONE)
+    osc = orclib.OracleScene(sd2)
+    ref = osc.render(160, 120, 1, abi.RT_PHONG, abi.RT_JITTER_NONE, want_samples=False, want_primary=False)["rgba"]
+    osc.close()
+    assert moved.tobytes() == want.tobytes() and moved.tobytes() != first.tobytes()
+    assert (np.abs(moved[:, :, :3].astype(int) - ref[:, :, :3].astype(int)).max(axis=2) <= 1).mean() >= 0.999
+
+
+def test_textured_mesh():
+    """image_map pigments: blitzcrank.pov (2850 textured smooth triangles, one 512x512 texture)."""
+    st = check_scene("blitzcrank", 200, 150)
+    assert st["shade_nodes"] > 0
+    check_scene("blitzcrank", 128, 96, samples=4, jitter=abi.RT_JITTER_HASH, seed=3)
+
+
+def test_texture_is_sampled_not_ignored():
+    sd = load("blitzcrank")
+    with ra.Scene(sd) as sc:
+        a, _ = sc.render(160, 120, 1, abi.RT_PHONG, abi.RT_JITTER_NONE)
+    sd.textures[0]["rgba"] = np.full_like(sd.textures[0]["rgba"], 255)
+    with ra.Scene(sd) as sc:
+        b, _ = sc.render(160, 120, 1, abi.RT_PHONG, abi.RT_JITTER_NONE)
+    assert (a != b).any()

@@ -144,6 +144,43 @@ def test_parser_on_reference_scenes(name):
     assert got.equals(scene(name))
 
 
+def test_texture_names_and_coordinates_from_the_parser():
+    got = ra.parse_pov(os.path.join(GOLD, "pov", "textured.pov"))
+    assert [t["name"] for t in got.textures] == ["checker.bmp", "other.bmp"]
+    assert got.triangles["mod"]["mat"]["tex_id"].tolist() == [0, 1, 0, -1]
+    assert got.triangles["vt2"][0].tolist() == [1.0, 0.0] and got.triangles["vt3"][3].tolist() == [0.0, 0.0]
+    assert got.smooth_triangles["vt3"][0].tolist() == [0.5, 1.0]
+    if os.path.exists(os.path.join(GOLD, "pov", "textured.expected.npz")):
+        assert got.equals(ra.SceneData.load(os.path.join(GOLD, "pov", "textured.expected.npz")))
+
+
+def test_bmp_loader(tmp_path):
+    """readBMP (kernel.cu:35-61): 54-byte header, bottom-up BGR rows -> r, g, b, 0 in file order."""
+    w, h = 4, 2
+    rng = np.random.default_rng(1)
+    bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    hdr = bytearray(54)
+    hdr[0:2] = b"BM"
+    hdr[10:14] = (54).to_bytes(4, "little"); hdr[14:18] = (40).to_bytes(4, "little")
+    hdr[18:22] = w.to_bytes(4, "little"); hdr[22:26] = h.to_bytes(4, "little")
+    hdr[26:28] = (1).to_bytes(2, "little"); hdr[28:30] = (24).to_bytes(2, "little")
+    path = tmp_path / "t.bmp"
+    path.write_bytes(bytes(hdr) + bgr.tobytes())
+    px = ra.load_bmp(path)
+    assert px.shape == (h, w, 4)
+    assert (px[:, :, :3] == bgr[:, :, ::-1]).all() and (px[:, :, 3] == 0).all()
+    with pytest.raises(ra.RaytracerError):
+        ra.load_bmp(tmp_path / "missing.bmp")
+
+
+def test_texture_reference_without_pixels_is_rejected():
+    sd = scene("blitzcrank")
+    sd.textures[0]["rgba"] = None
+    with pytest.raises(ra.RaytracerError) as e:
+        ra.Scene(sd, host_only=True)
+    assert e.value.code == abi.RT_ERR_BAD_ARGUMENT
+
+
 def test_scene_round_trip(tmp_path):
     sd = scene("cornell")
     p = str(tmp_path / "s.npz")

@@ -36,13 +36,14 @@ def classes():
     return np.load(os.path.join(GOLD, "classes.npz"))
 
 
-@pytest.mark.parametrize("name", ["transforms", "box", "cornell", "bunny_small_tris", "iceBot", "balls2"])
+@pytest.mark.parametrize("name", ["transforms", "box", "cornell", "bunny_small_tris", "iceBot", "balls2", "blitzcrank"])
 def test_primitive_known_answers(classes, name):
     osc = orclib.OracleScene(scene(name))
     try:
         prims = classes[f"{name}_prims"]
         rays, ts, nrm = classes[f"{name}_rays"], classes[f"{name}_t"], classes[f"{name}_normal"]
-        bbox, cen = classes[f"{name}_bbox"], classes[f"{name}_center"]
+        bbox, cen, uvs = classes[f"{name}_bbox"], classes[f"{name}_center"], classes[f"{name}_uv"]
+        uv = np.zeros(2, np.float32)
         a, b = np.zeros(3, np.float32), np.zeros(3, np.float32)
         hits = 0
         for i, p in enumerate(prims):
@@ -59,6 +60,9 @@ def test_primitive_known_answers(classes, name):
                     hits += 1
                     orclib.orc().orc_prim_normal(osc.h, p, o.ctypes.data_as(fp), d.ctypes.data_as(fp), C.c_float(t), a.ctypes.data_as(fp))
                     assert bits(a).tolist() == bits(nrm[i, k]).tolist(), f"normal of prim {p} ray {k}"
+                    if uvs[i, k].any():
+                        orclib.orc().orc_prim_uv(osc.h, p, o.ctypes.data_as(fp), d.ctypes.data_as(fp), C.c_float(t), uv.ctypes.data_as(fp))
+                        assert bits(uv).tolist() == bits(uvs[i, k]).tolist(), f"uv of prim {p} ray {k}"
         assert hits > 0
     finally:
         osc.close()
@@ -104,6 +108,7 @@ def test_render_against_reference_tga(name):
         osc.close()
     diff = np.abs(got[:, :, :3].astype(np.int16) - want.astype(np.int16)).max(axis=2)
     frac = float((diff <= 1).mean())
+    print(f"{name}: {frac:.4f} of pixels within 1/255, mean abs difference {diff.mean():.2f}")
     assert frac >= TGA_FLOOR[name], f"{name}: {frac:.4f} of pixels within 1/255"
     # the images agree as pictures, not just in flat regions: mean absolute error stays small
     assert float(diff.mean()) < 10.0
@@ -136,3 +141,24 @@ def test_hash_jitter_known_values():
         orclib.orc().orc_jitter_uniforms(seed, idx, C.byref(u), C.byref(v))
         a, b = uniforms(idx, seed)
         assert (np.float32(u.value), np.float32(v.value)) == (a, b)
+
+
+def test_texture_filter_known_values():
+    """The restated tex2D: texel centres return the texel, halfway points the average, coordinates wrap."""
+    px = np.zeros((2, 4, 4), np.uint8)
+    px[0, :, 0] = [0, 255, 0, 255]
+    px[1, :, 1] = 255
+    tex = abi.Texture()
+    tex.width, tex.height, tex.rgba = 4, 2, px.ctypes.data
+    rgb = np.zeros(3, np.float32)
+
+    def at(u, v):
+        orclib.orc().orc_texture_sample(C.byref(tex), C.c_float(u), C.c_float(v), rgb.ctypes.data_as(fp))
+        return rgb.copy()
+
+    assert at(0.125, 0.25).tolist() == [0.0, 0.0, 0.0]                 # centre of texel (0, 0)
+    assert at(0.375, 0.25).tolist() == [1.0, 0.0, 0.0]                 # centre of texel (1, 0)
+    assert at(0.25, 0.25).tolist() == [0.5, 0.0, 0.0]                  # halfway between them
+    assert at(0.375, 0.75).tolist() == [0.0, 1.0, 0.0]                 # row 1
+    assert at(1.375, -0.75).tolist() == at(0.375, 0.25).tolist()       # wrap in both directions
+    assert at(0.0, 0.25).tolist() == [0.5, 0.0, 0.0]                   # the left edge blends with the last column

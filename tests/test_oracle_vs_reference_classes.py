@@ -148,3 +148,35 @@ def test_shaders_bit_exact(shading):
         orclib.orc().orc_shade(shading, *args, out0.ctypes.data_as(fp))
         orclib.ref().ref_shade(shading, *args, out1.ctypes.data_as(fp))
         assert bits(out0).tolist() == bits(out1).tolist(), (i, out0, out1)
+
+
+def test_texture_coordinates_bit_exact():
+    """Triangle::UVAt (Triangle.h:44-52) on the textured mesh: the reference's own code against the oracle."""
+    path = os.path.join(orclib.REFERENCE_DIR, "blitzcrank.pov")
+    if not os.path.exists(path):
+        pytest.skip("blitzcrank.pov not present")
+    sd = orclib.ref_parse(path)
+    assert [t["name"] for t in sd.textures] == ["blitz.bmp"]
+    assert (sd.smooth_triangles["mod"]["mat"]["tex_id"] == 0).all()
+    osc = orclib.OracleScene(sd)
+    rs = orclib.ref().ref_scene_create(C.byref(osc.desc))
+    try:
+        rng = np.random.default_rng(8)
+        c3, a2, b2 = np.zeros(3, np.float32), np.zeros(2, np.float32), np.zeros(2, np.float32)
+        hits = 0
+        for _ in range(2000):
+            p = int(rng.integers(len(sd.spheres), osc.n_bvh_prims))
+            orclib.orc().orc_prim_center(osc.h, p, c3.ctypes.data_as(fp))
+            o = rng.normal(0, 5, 3).astype(np.float32)
+            d = (c3 + rng.normal(0, 0.01, 3).astype(np.float32) - o).astype(np.float32)
+            t = orclib.orc().orc_prim_intersect(osc.h, p, o.ctypes.data_as(fp), d.ctypes.data_as(fp))
+            if t <= 0:
+                continue
+            hits += 1
+            orclib.orc().orc_prim_uv(osc.h, p, o.ctypes.data_as(fp), d.ctypes.data_as(fp), C.c_float(t), a2.ctypes.data_as(fp))
+            orclib.ref().ref_prim_uv(rs, p, o.ctypes.data_as(fp), d.ctypes.data_as(fp), C.c_float(t), b2.ctypes.data_as(fp))
+            assert bits(a2).tolist() == bits(b2).tolist()
+        assert hits > 500
+    finally:
+        orclib.ref().ref_scene_destroy(rs)
+        osc.close()
