@@ -41,7 +41,7 @@ enum {
    RT_ERR_BAD_SAMPLE_COUNT = 2, /* sampleCount is not a perfect square (kernel.cu:707-712) */
    RT_ERR_NO_DEVICE = 3,      /* no HIP device / HIP runtime failure at init      */
    RT_ERR_HIP = 4,            /* a HIP call failed; rt_last_error() has the text  */
-   RT_ERR_UNSUPPORTED = 5,    /* textured pigment (image_map) -- out of scope     */
+   RT_ERR_UNSUPPORTED = 5,    /* e.g. a .bmp that is not 24-bit uncompressed       */
    RT_ERR_PARSE = 6,          /* scene file missing or malformed                  */
    RT_ERR_IO = 7,
    RT_ERR_NO_CAMERA = 8,      /* the reference dereferences data->camera unchecked (kernel.cu:716) */
