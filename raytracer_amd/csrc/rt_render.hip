@@ -1,31 +1,26 @@
 /*
  * rt_render.hip -- the per-pixel render path on MI355X (gfx950, wave64).
  *
- * Replaces the reference's rayTrace megakernel and its helpers
- * (kernel.cu:67-382, 466-570) with a wavefront pipeline over ray queues:
+ * Replaces the reference's rayTrace megakernel and its helpers (kernel.cu:67-382, 466-570).  The reference
+ * gives every sample a thread that recurses to depth 6 (shadeObject<6> -> getReflection<5> -> ...); here a
+ * frame is four kinds of launches:
  *
- *   generate primary rays of a batch of tiles into a ray queue    (generateCameraRays, kernel.cu:477-498)
- *   extend   closest hit of every ray of a depth level          (getClosestIntersection, kernel.cu:83-200)
- *   shadow   one any-hit query per (light, shade node)          (isInShadow, kernel.cu:202-207)
- *   shade    material + light sum per node, spawns the          (shadeObject / getReflection / getRefraction,
- *            reflection / refraction rays of the next level      kernel.cu:209-276, 335-382)
- *   combine  bottom-up: colour = local*(1-refl-alpha)            (kernel.cu:375-376)
- *                     + refl*reflected + alpha*refracted
- *   resolve  s x s box filter to 8-bit                           (averageBufferColors, kernel.cu:545-570)
+ *   k_trace         every ray of the frame in one persistent launch: primary rays, made from the sample slot
+ *                   when a lane fetches it (generateCameraRays, kernel.cu:477-498); their closest hits
+ *                   (getClosestIntersection, kernel.cu:83-200); the reflection / refraction rays those spawn
+ *                   (getReflection / getRefraction, kernel.cu:209-276), to depth 6; and one shadow feeler per
+ *                   light per hit (isInShadow, kernel.cu:202-207).  Follow-up work of a hit goes onto a list
+ *                   private to the wave that found it, so waves never wait for each other.
+ *   k_light         the light sum of every hit with the shadow flags (the loop of shadeObject, kernel.cu:347-358;
+ *                   PhongShader.h, CookTorranceShader.h; getColor with textures, kernel.cu:323-332)
+ *   k_combine_tree  colour = total*(1-refl-alpha) + refl*reflected + alpha*refracted (kernel.cu:375-376) over
+ *                   each primary's bounce tree, children first: the reference's expression tree with the same
+ *                   operands in the same order, no float atomics
+ *   k_resolve       s x s box filter to 8 bits (averageBufferColors, kernel.cu:545-570)
  *
- * The reference recurses to depth 6 inside one thread; here each depth level
- * is one batch of launches and a node's children are indices into the next
- * level, so the final combine evaluates exactly the reference's expression
- * tree (same operands, same order) without recursion or float atomics.
- *
- * extend and shadow are the same persistent-thread traversal kernel (k_trace)
- * over a ray queue: a wave keeps 64 rays in flight, and as soon as enough of its
- * lanes have finished it pulls the next rays of the queue into the idle lanes
- * (one atomic per refill), so long and short rays do not stall each other.
- * Each ray still walks the tree in the reference's visiting order (near child
- * first with its `<=` tie rule, deferred sibling re-checked against the current
- * t) because near-ties between primitives are resolved by visiting order.  The
- * per-lane stack of deferred siblings lives in LDS, one column per lane.
+ * Each ray walks the tree in the reference's visiting order (near child first with its `<=` rule, a deferred
+ * sibling taken only if still closer than the hit so far), because the reference resolves near-ties between
+ * primitives by visiting order.  The per-lane stack of deferred siblings lives in LDS, one column per lane.
  */
 #include <hip/hip_runtime.h>
 

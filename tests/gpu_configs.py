@@ -1,4 +1,4 @@
-"""Ad-hoc (not a test): frame times of the larger BASELINE configurations' stand-ins on one GPU."""
+"""Ad-hoc (not a test): frame times of the larger benchmark configurations' stand-ins on one GPU."""
 import os
 import sys
 import time

@@ -1,6 +1,6 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
 
-Bars (BASELINE north_star): closest-hit primitive ids of primary rays bit-exact (and, here, also the
+Bars: closest-hit primitive ids of primary rays bit-exact (and, here, also the
 hit distances bit for bit); output pixels within 1/255 per channel on >= 99.9 % of pixels.  Float
 sample colours may differ only by the device's powf/expf/ versus glibc's (tolerance stated below).
 """
