@@ -221,9 +221,9 @@ __device__ __forceinline__ F3 normal_at(const DScene &sc, int id, const Ray &ray
 }
 
 /* The overlap rule of kernel.cu:108-122: of two hits closer than EQUAL_EPSILON the one whose normal
- * faces the eye more wins.  Rare (a few percent of rays), so kept out of line; it takes the arrays by
- * value so that the caller's scene view stays in registers. */
-__device__ __noinline__ bool tie_prefers_new(const rt_dev_prim *prims, const rt_dev_xform *xforms, const rt_dev_shade *shades,
+ * faces the eye more wins.  Rare (a few rays in a thousand): the traversal loop resolves it in a phase of its
+ * own behind the leaf step, so that its registers do not add to the leaf step's. */
+__device__ __forceinline__ bool tie_prefers_new(const rt_dev_prim *prims, const rt_dev_xform *xforms, const rt_dev_shade *shades,
                                              float ox, float oy, float oz, float dx, float dy, float dz,
                                              int old_prim, float old_t, int new_prim, float new_t)
 {
@@ -380,26 +380,6 @@ __device__ __forceinline__ Ray load_qray(const QRay *q, long long i)
    return r;
 }
 
-/* what a primitive test does to the traversal state (kernel.cu:104-134): returns true when the ray is done early */
-__device__ __forceinline__ bool leaf_update(const DScene &sc, const Ray &ray, int prim, float dist, float toBeat, float &t,
-                                            int &closest, unsigned &n_ties)
-{
-   bool take = false;
-   if (is_equal(t, dist)) {
-      n_ties++;
-      if (closest >= 0)
-         take = tie_prefers_new(sc.prims, sc.xforms, sc.shades, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z,
-                                closest, t, prim, dist);
-   } else {
-      take = dist < t && above_zero(dist);
-   }
-   if (take) {
-      t = dist; closest = prim;
-      return t < toBeat;                                 /* kernel.cu:117-121, 128-132 */
-   }
-   return false;
-}
-
 /* planes after the tree: kernel.cu:189-196 (no tie rule, no toBeat exit) */
 __device__ __forceinline__ void plane_scan(const DScene &sc, const Ray &ray, float &t, int &closest)
 {
@@ -410,10 +390,9 @@ __device__ __forceinline__ void plane_scan(const DScene &sc, const Ray &ray, flo
 }
 
 /* The reflection and refraction rays of a hit (getReflection kernel.cu:214-216, getRefraction
- * kernel.cu:239-257).  Out of line and fed by value, like the tie rule, so that the traversal loop's
- * registers are not sized by it. */
+ * kernel.cu:239-257). */
 struct BounceRays { float ro[3], rd[3], to[3], td[3]; int want_refl, want_refr; };
-__device__ __noinline__ BounceRays bounce_rays(const rt_dev_prim *prims, const rt_dev_xform *xforms, const rt_dev_shade *shades,
+__device__ __forceinline__ BounceRays bounce_rays(const rt_dev_prim *prims, const rt_dev_xform *xforms, const rt_dev_shade *shades,
                                                const rt_dev_plane *planes, int n_prims,
                                                float ox, float oy, float oz, float dx, float dy, float dz, int prim, float t,
                                                float m_refl, float m_refr, float m_ior)
@@ -732,6 +711,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       bool at_leaf = active && cur < 0;
       if (__ballot(at_leaf) != 0) {
          if (COUNT) { wl++; if (active) ray_steps++; }
+         bool tie = false, take = false, tested = false;
+         float leaf_dist = 0.0f;
          if (at_leaf) {
             float dist = prim_intersect(sc, ~cur, c.r);
             if (OUT == OUT_CHAIN && mode == MODE_SETUP) {
@@ -744,14 +725,32 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                   if (cur == RT_ROOT_EMPTY) finish(false);
                }
             } else {
+               /* what the test does to the traversal state, kernel.cu:104-134; a near-tie with the hit so far is
+                * only marked here and decided below */
                bool shadow = OUT == OUT_CHAIN && mode != MODE_EXTEND;
                if (COUNT) { if (shadow) nps++; else np++; }
-               unsigned ties = 0;
-               bool early = leaf_update(sc, c.r, ~cur, dist, toBeat, t, closest, ties);
-               if (COUNT) { if (shadow) nts += ties; else nt += ties; }
-               if (early) finish(true);
-               else pop();
+               if (is_equal(t, dist)) {
+                  if (COUNT) { if (shadow) nts++; else nt++; }
+                  tie = closest >= 0;
+               } else {
+                  take = dist < t && above_zero(dist);
+               }
+               leaf_dist = dist;
+               tested = true;
             }
+         }
+         if (__ballot(tie) != 0) {
+            if (tie) {
+               take = tie_prefers_new(sc.prims, sc.xforms, sc.shades, c.r.o.x, c.r.o.y, c.r.o.z, c.r.d.x, c.r.d.y, c.r.d.z,
+                                      closest, t, ~cur, leaf_dist);
+               tie = false;
+            }
+         }
+         if (tested) {
+            bool early = false;
+            if (take) { t = leaf_dist; closest = ~cur; early = t < toBeat; }      /* kernel.cu:117-121, 128-132 */
+            if (early) finish(true);
+            else pop();
          }
       }
    }
