@@ -174,6 +174,8 @@ typedef struct rt_scene_info {
    int32_t root;             /* node index, or ~prim when the tree is a single leaf, or INT32_MIN when empty */
    uint64_t device_bytes;
    float ms_build_host, ms_upload;
+   float ms_build_device;    /* RT_SCENE_GPU_BVH: the device kernels of the tree build (ms_build_host then covers the rest) */
+   int32_t pad;
 } rt_scene_info;
 
 /* Flattened BVH node, 64 bytes: both children's boxes live in the parent so
@@ -193,10 +195,13 @@ typedef struct rt_scene rt_scene;   /* opaque: host copy + device-resident flat 
 enum {
    RT_SCENE_DEFAULT = 0,
    RT_SCENE_COUNTERS = 1,    /* traversal statistics in rt_stats (a slower variant of the kernel) */
-   RT_SCENE_FAST_BVH = 2     /* NOT the reference's tree: a surface-area-heuristic BVH over the same primitives.
+   RT_SCENE_FAST_BVH = 2,    /* NOT the reference's tree: a surface-area-heuristic BVH over the same primitives.
                               * Far fewer box tests per ray, but near-ties between primitives (kernel.cu:108-122)
                               * are resolved by visiting order, so a few silhouette samples differ from the
                               * reference; never part of a parity claim */
+   RT_SCENE_GPU_BVH = 4      /* NOT the reference's tree either: a linear BVH (Morton codes + radix tree) built on the
+                              * device in milliseconds; same caveat as RT_SCENE_FAST_BVH, lower tree quality, for scenes
+                              * that change every frame.  Ignored by rt_scene_create_host */
 };
 
 /* ---- entry points ------------------------------------------------------ */

@@ -76,6 +76,7 @@ typedef struct rt_flat_scene {
    rt_material *materials;     /* n_materials (deduplicated) */
    rt_dev_light *lights;       /* n_lights */
    int32_t *leaf_order;        /* n_prims: geomList after formBVH's sort rounds */
+   float *prim_boxes;          /* n_prims x {min xyz, max xyz}: getBoundingBox() of every primitive (the device builder's input) */
    int32_t n_textures;
    rt_dev_texinfo *tex_info;   /* n_textures */
    uint8_t *texels;            /* 4 bytes per texel, all textures back to back */
@@ -94,6 +95,8 @@ int rt_flatten_scene(const rt_scene_desc *desc, rt_flat_scene *out);
 int rt_flatten_scene_ex(const rt_scene_desc *desc, int flags, rt_flat_scene *out);
 void rt_flat_scene_free(rt_flat_scene *fs);
 void rt_set_error(const char *fmt, ...);
+/* device-side linear BVH over n >= 2 boxes (rt_lbvh.hip) */
+int rt_lbvh_build(const float *boxes_host, int n, rt_bvh_node **nodes_out, int32_t **order_out, int *depth_out, float *ms_out);
 #ifdef __cplusplus
 }
 #endif

@@ -1064,7 +1064,7 @@ struct rt_scene {
    int has_camera;
    void *dev_blob;          /* one allocation holding every scene array */
    size_t dev_bytes;
-   float ms_build_host, ms_upload;
+   float ms_build_host, ms_upload, ms_build_device;
    Arena arena;             /* per-frame queues; grown on demand, reused across frames */
    unsigned long long *d_ctr;    /* work counters of the chunks in flight: RT_RING x 8 words (see ChunkCtr) */
    unsigned long long *d_stats;
@@ -1119,7 +1119,7 @@ extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
    if (!s) return RT_ERR_BAD_ARGUMENT;
    memset(&s->host, 0, sizeof s->host);
    memset(&s->d, 0, sizeof s->d);
-   s->device = -1; s->flags = 0; s->streams_ok = false;
+   s->device = -1; s->flags = 0; s->streams_ok = false; s->ms_build_device = 0.0f;
    s->dev_blob = nullptr; s->dev_bytes = 0; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
    s->camera = desc->camera; s->has_camera = desc->has_camera; s->ms_upload = 0;
    auto t0 = std::chrono::steady_clock::now();
@@ -1142,13 +1142,25 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    rt_scene *s = new (std::nothrow) rt_scene();
    if (!s) return RT_ERR_BAD_ARGUMENT;
    memset(&s->host, 0, sizeof s->host);
-   s->device = device; s->flags = flags; s->streams_ok = false;
+   s->device = device; s->flags = flags; s->streams_ok = false; s->ms_build_device = 0.0f;
    s->dev_blob = nullptr; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
    s->camera = desc->camera; s->has_camera = desc->has_camera;
 
    auto t0 = std::chrono::steady_clock::now();
    int st = rt_flatten_scene_ex(desc, flags, &s->host);
    if (st != RT_OK) { delete s; return st; }
+   if ((flags & RT_SCENE_GPU_BVH) && s->host.n_prims > 1) {
+      rt_bvh_node *nodes = nullptr; int32_t *order = nullptr; int depth = 0; float ms = 0.0f;
+      st = rt_lbvh_build(s->host.prim_boxes, s->host.n_prims, &nodes, &order, &depth, &ms);
+      if (st != RT_OK) { rt_flat_scene_free(&s->host); delete s; return st; }
+      free(s->host.nodes); free(s->host.leaf_order);
+      s->host.nodes = nodes; s->host.leaf_order = order;
+      s->host.n_nodes = s->host.n_prims - 1; s->host.tree_depth = depth; s->host.root = 0;
+      s->ms_build_device = ms;
+      for (int k = 0; k < s->host.n_nodes; k++)
+         for (int j = 0; j < 12; j++)
+            if (!(std::fabs(s->host.nodes[k].lmin[j]) <= 1.099511627776e12f)) s->host.bounds_in_range = 0;
+   }
    auto t1 = std::chrono::steady_clock::now();
    s->ms_build_host = std::chrono::duration<float, std::milli>(t1 - t0).count();
 
@@ -1209,7 +1221,7 @@ extern "C" int rt_scene_get_info(const rt_scene *s, rt_scene_info *info)
    info->n_bvh_prims = s->host.n_prims; info->n_planes = s->host.n_planes; info->n_lights = s->host.n_lights;
    info->n_nodes = s->host.n_nodes; info->n_materials = s->host.n_materials; info->tree_depth = s->host.tree_depth;
    info->root = s->host.root; info->device_bytes = s->dev_bytes;
-   info->ms_build_host = s->ms_build_host; info->ms_upload = s->ms_upload;
+   info->ms_build_host = s->ms_build_host; info->ms_upload = s->ms_upload; info->ms_build_device = s->ms_build_device;
    return RT_OK;
 }
 

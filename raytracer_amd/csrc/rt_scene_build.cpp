@@ -446,7 +446,9 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
    std::vector<rt_bvh_node> flat;
    int32_t root = RT_ROOT_EMPTY;
    int depth = 0;
-   if (n > 0 && (flags & RT_SCENE_FAST_BVH)) {
+   if (n > 1 && (flags & RT_SCENE_GPU_BVH)) {
+      root = 0;      /* the tree is built on the device by the caller (rt_lbvh_build) from prim_boxes */
+   } else if (n > 0 && (flags & RT_SCENE_FAST_BVH)) {
       std::vector<TreeNode> pool;
       pool.reserve((size_t)(2 * n));
       int levels = 0; while ((1 << levels) < n) levels++;
@@ -539,6 +541,11 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
    order.resize((size_t)n);
    out->leaf_order = copy_out(order);
    {
+      std::vector<float> pb((size_t)n * 6);
+      for (int i = 0; i < n; i++) { put(&pb[(size_t)i * 6], b.boxes[(size_t)i].mn); put(&pb[(size_t)i * 6 + 3], b.boxes[(size_t)i].mx); }
+      out->prim_boxes = copy_out(pb);
+   }
+   {
       std::vector<rt_dev_texinfo> info((size_t)d->n_textures);
       std::vector<uint8_t> texels;
       for (int i = 0; i < d->n_textures; i++) {
@@ -561,6 +568,6 @@ extern "C" void rt_flat_scene_free(rt_flat_scene *fs)
 {
    if (!fs) return;
    free(fs->nodes); free(fs->prims); free(fs->xforms); free(fs->shades); free(fs->planes);
-   free(fs->materials); free(fs->lights); free(fs->leaf_order); free(fs->tex_info); free(fs->texels);
+   free(fs->materials); free(fs->lights); free(fs->leaf_order); free(fs->tex_info); free(fs->texels); free(fs->prim_boxes);
    memset(fs, 0, sizeof *fs);
 }

@@ -14,8 +14,9 @@ w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 108
 shading = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 samples = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 fast = os.environ.get("PROBE_FAST_BVH", "0") == "1"
+gpu = os.environ.get("PROBE_GPU_BVH", "0") == "1"
 sd = ra.SceneData.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes", name + ".npz"))
-with ra.Scene(sd, fast_bvh=fast) as sc:
+with ra.Scene(sd, fast_bvh=fast, gpu_bvh=gpu) as sc:
     print(sc.info())
     best = None
     for i in range(5):
@@ -26,7 +27,7 @@ with ra.Scene(sd, fast_bvh=fast) as sc:
     print(f"{name} {w}x{h} spp{samples}: ms_total {st['ms_total']:.3f}  trace {st['ms_trace']:.3f} ({st['launches_trace']} launches)  "
           f"light {st['ms_light']:.3f} combine {st['ms_combine']:.3f} resolve {st['ms_resolve']:.3f}  "
           f"rays {st['rays_total']} -> {st['rays_total'] / st['ms_total'] / 1e3:.1f} Mrays/s")
-with ra.Scene(sd, counters=True, fast_bvh=fast) as sc:
+with ra.Scene(sd, counters=True, fast_bvh=fast, gpu_bvh=gpu) as sc:
     frame, st = sc.render(w, h, samples, shading, abi.RT_JITTER_HASH)
     n_ext = st['rays_primary'] + st['rays_reflect'] + st['rays_refract']
     nv, npr = st['node_visits'] + st['node_visits_shadow'], st['prim_tests'] + st['prim_tests_shadow']

@@ -23,14 +23,15 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
+@pytest.mark.parametrize("builder", ["fast_bvh", "gpu_bvh"])
 @pytest.mark.parametrize("name", ["cornell", "balls2", "bunny", "iceBot", "dragon_large_tris"])
-def test_fast_tree_agrees_with_reference_tree(name):
+def test_fast_tree_agrees_with_reference_tree(name, builder):
     sd = ra.SceneData.load(os.path.join(GOLDEN, "scenes", name + ".npz"))
     w, h = 320, 240
     with ra.Scene(sd, counters=True) as sc:
         prim0, t0 = sc.trace_primary(w, h)
         frame0, st0 = sc.render(w, h, 1, abi.RT_PHONG, abi.RT_JITTER_NONE)
-    with ra.Scene(sd, counters=True, fast_bvh=True) as sc:
+    with ra.Scene(sd, counters=True, **{builder: True}) as sc:
         info = sc.info()
         prim1, t1 = sc.trace_primary(w, h)
         frame1, st1 = sc.render(w, h, 1, abi.RT_PHONG, abi.RT_JITTER_NONE)
@@ -42,7 +43,7 @@ def test_fast_tree_agrees_with_reference_tree(name):
     assert (prim0 == prim1).mean() >= 0.995
     diff = np.abs(frame0[:, :, :3].astype(int) - frame1[:, :, :3].astype(int)).max(axis=2)
     agree = float((diff <= 1).mean())
-    print(f"{name}: ids equal {(prim0 == prim1).mean():.4f}, pixels within 1/255 {agree:.4f}, "
+    print(f"{name} [{builder}]: ids equal {(prim0 == prim1).mean():.4f}, pixels within 1/255 {agree:.4f}, "
           f"box-test records per ray {st0['node_visits'] / max(1, st0['rays_primary'] + st0['rays_reflect'] + st0['rays_refract']):.1f} -> "
           f"{st1['node_visits'] / max(1, st1['rays_primary'] + st1['rays_reflect'] + st1['rays_refract']):.1f}")
     assert agree >= 0.80
@@ -61,3 +62,17 @@ def test_fast_tree_makes_the_large_height_field_tractable():
     assert info["tree_depth"] <= 18 + 8
     assert (st["node_visits"] + st["node_visits_shadow"]) / n_rays < 200
     assert len(np.unique(frame[:, :, :3].reshape(-1, 3), axis=0)) > 1000
+
+
+def test_device_build_of_a_large_scene():
+    """A million triangles: the device builder takes milliseconds, and the picture matches the host SAH tree's."""
+    sd = synth.terrain(1000, 500, lights_per_side=2)
+    with ra.Scene(sd, gpu_bvh=True) as sc:
+        info = sc.info()
+        prim_g, t_g = sc.trace_primary(320, 180)
+    assert info["n_nodes"] == 999999 and 0 < info["ms_build_device"] < 100.0
+    with ra.Scene(sd, fast_bvh=True) as sc:
+        prim_s, t_s = sc.trace_primary(320, 180)
+    assert ((prim_g >= 0) == (prim_s >= 0)).mean() >= 0.9995
+    both = (prim_g >= 0) & (prim_s >= 0)
+    assert np.abs(t_g[both] - t_s[both]).max() <= 0.0101
