@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-bvh", action="store_true", help="skip the informational fast-tree frames (keeps a profile of this command to the benchmark's own launches)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks share cuda:0 and exchange over gloo (host-staged): checks the N > 1 code path on a 1-GPU box")
     args = ap.parse_args()
@@ -215,7 +216,7 @@ def main():
                             "The kernel is bound by VALU issue (about 70 % busy) and dependent-fetch latency"}
         if world == 1 and not args.no_cpu_baseline:
             baseline = cpu_baseline(sd, shading, jitter)
-        if world == 1:
+        if world == 1 and not args.no_fast_bvh:
             # informational only: the same frame with the opt-in SAH tree (not the reference's tree, not a parity mode)
             fscene = ra.Scene(sd, device=local_rank, fast_bvh=True)
             best = None
