@@ -4,6 +4,7 @@ Bars: closest-hit primitive ids of primary rays bit-exact (and, here, also the
 hit distances bit for bit); output pixels within 1/255 per channel on >= 99.9 % of pixels.  Float
 sample colours may differ only by the device's powf/expf/ versus glibc's (tolerance stated below).
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -149,6 +150,29 @@ def test_bad_sample_count_and_errors():
     with pytest.raises(ra.RaytracerError) as e:
         ra.launch_kernel(sd, ra.PHONG, 32, 32, out, 1)
     assert e.value.code == abi.RT_ERR_NO_CAMERA
+
+
+def test_extreme_sizes():
+    """One pixel with 16 samples, a 1-row frame narrower than a tile, a frame beyond the 2^30-sample limit,
+    and a tile selection past the end of the grid (nothing to render, not an error)."""
+    sd = load("simple")
+    osc = orclib.OracleScene(sd)
+    with ra.Scene(sd, device=0) as sc:
+        for (w, h, spp) in ((1, 1, 16), (5, 1, 4), (1, 37, 1)):
+            got, _ = sc.render(w, h, spp, jitter=abi.RT_JITTER_NONE)
+            want = osc.render(w, h, spp, jitter=abi.RT_JITTER_NONE, want_samples=False, want_primary=False)["rgba"]
+            assert got.shape == (h, w, 4)
+            assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+        with pytest.raises(ra.RaytracerError) as e:
+            sc.render_device(ra.make_params(1 << 16, 1 << 15, 1), 0x1000)
+        assert e.value.code == abi.RT_ERR_TOO_LARGE
+        out = np.full((32, 32, 4), 9, np.uint8)
+        p = ra.make_params(32, 32, 1, tile_first=5, tile_stride=7)
+        st = abi.Stats()
+        lib = abi.load_library()
+        assert lib.rt_render(sc._h, C.byref(p), out.ctypes.data, C.byref(st)) == abi.RT_OK
+        assert st.samples == 0
+        assert ra.tile_count(32, 32, 5, 7) == 0 and ra.tile_count(33, 32, 1, 2) == 1
 
 
 def test_depth_limit():
