@@ -471,16 +471,23 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          if (OUT == OUT_CHAIN) pend = true;
       }
    };
+   /* The entry a pop would take first, read ahead of the work that decides whether a pop happens: a step either
+    * pushes or pops, never both, so the top of the stack at the start of a step is the entry its pop starts with,
+    * and the LDS round trip overlaps the node or primitive fetch instead of following it. */
+   auto peek = [&]() {
+      StackEntry e = stack[(sp > 0 ? sp - 1 : 0) * stride];
+      asm volatile("" : "+v"(e.child), "+v"(e.dist));      /* one 64-bit read, issued here */
+      return e;
+   };
    /* pop deferred siblings until one is still closer than t (kernel.cu:160-186); none left = done */
-   auto pop = [&]() {
-      /* the first try is straight-line code (nearly always enough: an entry goes stale only when t has shrunk
+   auto pop = [&](StackEntry top) {
+      /* the first try uses the entry read ahead (nearly always enough: an entry goes stale only when t has shrunk
        * since it was pushed); the loop behind it walks past stale entries */
       bool found = false;
       if (sp > 0) {
          sp--;
-         StackEntry e = stack[sp * stride];
-         found = e.dist < t;
-         if (found) cur = e.child;
+         found = top.dist < t;
+         if (found) cur = top.child;
       }
       if (!found) {
          while (sp > 0) {
@@ -500,6 +507,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       float4 nb = *reinterpret_cast<const float4 *>(rec + 16);
       float4 nc = *reinterpret_cast<const float4 *>(rec + 32);
       int2 ch = *reinterpret_cast<const int2 *>(rec + 48);
+      StackEntry top = peek();
       if (COUNT) { if (OUT == OUT_CHAIN && mode != MODE_EXTEND) nvs++; else nv++; }
       float left, right;
       if (VARIANT == 2) {
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          stack[sp * stride] = e; sp++;
       }
       if (goR || goL) cur = goR ? ch.y : ch.x;
-      else pop();
+      else pop(top);
    };
    /* OUT_CHAIN: every lane that finished since the last call writes its spawn record and appends its bounce rays */
    auto spawn_stage = [&]() {
@@ -713,7 +721,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          if (COUNT) { wl++; if (active) ray_steps++; }
          bool tie = false, take = false, tested = false;
          float leaf_dist = 0.0f;
+         StackEntry top; top.child = 0; top.dist = 0.0f;
          if (at_leaf) {
+            top = peek();
             float dist = prim_intersect(sc, ~cur, c.r);
             if (OUT == OUT_CHAIN && mode == MODE_SETUP) {
                /* the feeler against its own surface (kernel.cu:351).  A feeler that misses it (-1) can never be
@@ -750,7 +760,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             bool early = false;
             if (take) { t = leaf_dist; closest = ~cur; early = t < toBeat; }      /* kernel.cu:117-121, 128-132 */
             if (early) finish(true);
-            else pop();
+            else pop(top);
          }
       }
    }
