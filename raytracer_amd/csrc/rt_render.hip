@@ -501,12 +501,15 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    /* one node step of this lane (kernel.cu:136-158) */
    auto node_step = [&](auto variant_tag) {
       constexpr int VARIANT = decltype(variant_tag)::value;
-      /* 56 of the record's 64 bytes: two boxes and the two child references */
+      /* the record: two boxes and the two child references.  The last fetch is kept whole until the box tests are
+       * done: the compiler fetches 16 bytes for the 8 that are used, and would otherwise hand the two spare
+       * registers out at once -- to the stack read below, which then had to wait for the fetch it should overlap */
       const char *rec = reinterpret_cast<const char *>(sc.nodes) + ((unsigned)cur << 6);
       float4 na = *reinterpret_cast<const float4 *>(rec);
       float4 nb = *reinterpret_cast<const float4 *>(rec + 16);
       float4 nc = *reinterpret_cast<const float4 *>(rec + 32);
-      int2 ch = *reinterpret_cast<const int2 *>(rec + 48);
+      int4 tail = *reinterpret_cast<const int4 *>(rec + 48);
+      int2 ch; ch.x = tail.x; ch.y = tail.y;
       StackEntry top = peek();
       if (COUNT) { if (OUT == OUT_CHAIN && mode != MODE_EXTEND) nvs++; else nv++; }
       float left, right;
@@ -520,6 +523,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       /* kernel.cu:148-158 as predicates.  A child that is not ahead (box value not above zero) gets distance
        * +inf; then "right first on `<=`" is r <= l, "closer than the hit so far" is < t (t is finite or
        * FLT_MAX), and the other child is deferred exactly when its distance is not +inf. */
+      asm volatile("" : : "v"(tail.z), "v"(tail.w));
       const float inf = __builtin_inff();
       float l = above_zero(left) ? left : inf, r = above_zero(right) ? right : inf;
       bool goR = r <= l && r < t;
