@@ -708,17 +708,19 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          continue;
       }
       /* ---- node steps ---- */
+      /* the box-test variant is the same for a whole burst (the flags only change in a refill): one loop each */
+      auto burst_loop = [&](auto variant_tag) {
 #pragma unroll 1
-      for (int burst = 0; burst < a.node_burst; burst++) {
-         bool in_node = active && cur >= 0;
-         if (__ballot(in_node) == 0) break;
-         if (COUNT) { wn++; if (active) ray_steps++; }
-         if (in_node) {
-            if (wave_lit) node_step(std::integral_constant<int, 2>());
-            else if (wave_par) node_step(std::integral_constant<int, 1>());
-            else node_step(std::integral_constant<int, 0>());
+         for (int burst = 0; burst < a.node_burst; burst++) {
+            bool in_node = active && cur >= 0;
+            if (__ballot(in_node) == 0) break;
+            if (COUNT) { wn++; if (active) ray_steps++; }
+            if (in_node) node_step(variant_tag);
          }
-      }
+      };
+      if (wave_lit) burst_loop(std::integral_constant<int, 2>());
+      else if (wave_par) burst_loop(std::integral_constant<int, 1>());
+      else burst_loop(std::integral_constant<int, 0>());
       /* ---- leaf step ---- */
       bool at_leaf = active && cur < 0;
       if (__ballot(at_leaf) != 0) {
