@@ -324,6 +324,7 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2 };
 
 #define RT_STEP_CAP (1ULL << 28)
 #define RT_REFILL_IDLE 20   /* pull new rays once this many lanes of the wave are idle */
+#define RT_CUR_IDLE ((int)0x80000000)
 #define RT_NODE_BURST 12    /* node steps between two leaf steps / refill checks */
 #define RT_LIFO_CAP 512     /* spawned rays a wave can hold back; 64 lanes x 5 spawning levels = 320 is the most a
                              * newest-first drain leaves waiting */
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    RayCtx c;
    c.r.o = mk3(0, 0, 0); c.r.d = mk3(1, 1, 1); c.yx = c.yy = c.yz = 1.0f; c.par = 0; c.fast = true;
    float t = FLT_MAX, toBeat = -FLT_MAX;
-   int closest = -1, cur = 0, sp = 0, tag = 0;
+   int closest = -1, cur = RT_CUR_IDLE, sp = 0, tag = 0;   /* cur: node index, ~primitive, or RT_CUR_IDLE while the lane has no ray */
    int mode = MODE_EXTEND;             /* OUT_CHAIN: what this lane's ray is */
    unsigned idx = 0;
    unsigned n_traced = 0, n_skipped = 0;                    /* OUT_CHAIN: shadow feelers this lane traced / skipped */
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    auto finish = [&](bool early) {
       if (COUNT) { max_ray_steps = ray_steps > max_ray_steps ? ray_steps : max_ray_steps; }
       if (!early) plane_scan(sc, c.r, t, closest);
-      active = false;
+      active = false; cur = RT_CUR_IDLE;
       if (OUT == OUT_CHAIN && mode != MODE_EXTEND) {
          a.flags[tag - 1] = less_than(t, toBeat) ? 1 : 0;            /* kernel.cu:206 */
       } else {
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       auto burst_loop = [&](auto variant_tag) {
 #pragma unroll 1
          for (int burst = 0; burst < a.node_burst; burst++) {
-            bool in_node = active && cur >= 0;
+            bool in_node = cur >= 0;                 /* idle lanes hold RT_CUR_IDLE */
             if (__ballot(in_node) == 0) break;
             if (COUNT) { wn++; if (active) ray_steps++; }
             if (in_node) node_step(variant_tag);
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                /* the feeler against its own surface (kernel.cu:351).  A feeler that misses it (-1) can never be
                 * reported shadowed: isFloatLessThan(closest, -1) is false for every accepted t.  The reference
                 * still walks the tree for it; that walk is skipped here and counted separately. */
-               if (dist == -1.0f) { a.flags[tag - 1] = 0; n_skipped++; active = false; }
+               if (dist == -1.0f) { a.flags[tag - 1] = 0; n_skipped++; active = false; cur = RT_CUR_IDLE; }
                else {
                   n_traced++; toBeat = dist; mode = MODE_SHADOW; cur = sc.root;
                   if (cur == RT_ROOT_EMPTY) finish(false);
