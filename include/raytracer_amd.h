@@ -166,6 +166,9 @@ typedef struct rt_stats {
    uint64_t wave_node_steps, wave_leaf_steps;
    /* the longest single ray, in wave steps it was in flight */
    uint64_t max_ray_steps;
+   /* most spawned rays / shadow items any wave held back at once (always filled); a frame that overflows the
+    * lists is rendered again with longer ones, see attempts */
+   uint64_t max_spawn_list;
 } rt_stats;
 
 typedef struct rt_scene_info {

@@ -91,7 +91,7 @@ class Stats(C.Structure):
                 ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64), ("tie_events", C.c_uint64),
                 ("node_visits_shadow", C.c_uint64), ("prim_tests_shadow", C.c_uint64), ("tie_events_shadow", C.c_uint64),
                 ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64),
-                ("max_ray_steps", C.c_uint64)]
+                ("max_ray_steps", C.c_uint64), ("max_spawn_list", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

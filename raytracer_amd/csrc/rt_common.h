@@ -95,8 +95,6 @@ int rt_flatten_scene(const rt_scene_desc *desc, rt_flat_scene *out);
 int rt_flatten_scene_ex(const rt_scene_desc *desc, int flags, rt_flat_scene *out);
 void rt_flat_scene_free(rt_flat_scene *fs);
 void rt_set_error(const char *fmt, ...);
-/* device numbering of the tree: the k_top nodes nearest the root first (breadth-first), the rest in host order */
-void rt_order_nodes_for_device(const rt_bvh_node *in, int n, int root, int k_top, rt_bvh_node *out);
 /* device-side linear BVH over n >= 2 boxes (rt_lbvh.hip) */
 int rt_lbvh_build(const float *boxes_host, int n, rt_bvh_node **nodes_out, int32_t **order_out, int *depth_out, float *ms_out);
 #ifdef __cplusplus

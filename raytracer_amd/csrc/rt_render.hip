@@ -90,8 +90,13 @@ struct SpawnRec {
 enum { ST_SHADOW_TRACED = 0, ST_SHADOW_SKIPPED, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES, ST_PRIMARY,
        ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
        ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW,
-       ST_ABORTED, ST_MAX_RAY_STEPS, ST_OVERFLOW, ST_NODES_PER_PRIMARY_X16,
-       ST_CLOCK_FIRST_START, ST_CLOCK_LAST_EXIT, ST_CLOCK_EXIT_SUM, ST_WAVES, ST_COUNT };
+       ST_ABORTED, ST_MAX_RAY_STEPS, ST_MAX_LIST, ST_OVERFLOW, ST_LIST_OVERFLOW, ST_NODES_PER_PRIMARY_X16,
+       ST_CLOCK_FIRST_START, ST_CLOCK_LAST_EXIT, ST_CLOCK_EXIT_SUM, ST_WAVES,
+#ifdef RT_DEBUG_EXIT_HIST
+       ST_HIST, ST_COUNT = ST_HIST + 48 };    /* when each wave of the traversal launch was done, in 0.25 ms bins */
+#else
+       ST_COUNT };
+#endif
 
 /* Statistics counters are replicated RT_STAT_REPL times (blocks spread over the replicas, the host
  * sums them) and bumped once per wave, so that counting does not serialise the kernels on one word. */
@@ -325,9 +330,10 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2 };
 #define RT_STEP_CAP (1ULL << 28)
 #define RT_REFILL_IDLE 20   /* pull new rays once this many lanes of the wave are idle */
 #define RT_CUR_IDLE ((int)0x80000000)
+#define RT_TAKE_OLDEST 64    /* lanes of a refill that take the oldest list entries: all of them */
+#define RT_LIST_CAP_FIRST 1024u   /* entries of a wave's list to begin with; doubled when a frame overflows it */
+#define RT_LIST_CAP_MAX 65536u
 #define RT_NODE_BURST 12    /* node steps between two leaf steps / refill checks */
-#define RT_LIFO_CAP 512     /* spawned rays a wave can hold back; 64 lanes x 5 spawning levels = 320 is the most a
-                             * newest-first drain leaves waiting */
 
 struct TraceArgs {
    QRay *rays;                  /* the queue; OUT_CHAIN appends spawned rays behind the first n */
@@ -338,7 +344,8 @@ struct TraceArgs {
    unsigned long long *next;    /* this launch's zeroed fetch counter */
    unsigned long long *stats;
    int refill_idle, node_burst; /* tuning: idle lanes that trigger a refill, node steps between two leaf steps */
-   int stack_depth;             /* entries per lane of the traversal stack (the LDS behind it is the OUT_CHAIN list) */
+   int take_oldest;             /* lanes of a refill that take the oldest list entries instead of the newest */
+   int stack_depth;             /* entries per lane of the traversal stack in LDS */
    /* OUT_CHAIN */
    DCamera cam;                 /* the first n entries are the primaries of grid `g`: made here, on fetch */
    DGrid g;
@@ -346,6 +353,10 @@ struct TraceArgs {
    unsigned *tail;              /* next free queue entry; starts at n */
    unsigned cap;                /* entries the queue has room for */
    int max_rec;
+   unsigned *lists;             /* one ring of list_cap (a power of two) entries per wave of the launch */
+   unsigned list_cap;
+   const int *tile_order;       /* when non-null: the order in which the launch's tiles are started (costliest first) */
+   unsigned per_tile;           /* samples of one tile */
 };
 
 __device__ __forceinline__ QRay load_qray_rec(const QRay *q, unsigned long long i)
@@ -437,11 +448,21 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    const int stride = RT_BLOCK;
    const unsigned lane = __lane_id();
    const unsigned long long below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
-   unsigned *lifo = reinterpret_cast<unsigned *>(lds_stack + (size_t)RT_BLOCK * a.stack_depth) + (threadIdx.x >> 6) * RT_LIFO_CAP;
-   int lifo_count = 0;                 /* wave-uniform */
+   /* OUT_CHAIN: this wave's list of spawned rays and shadow items still to be started, a ring of a.list_cap entries in
+    * global memory: entries head .. head+count-1 (wave-uniform).  Written with plain stores, read back past the
+    * CU's vector cache (the reader is another lane of the same wave, some refills later). */
+   unsigned *const list = a.lists ? a.lists + (size_t)(blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * a.list_cap : nullptr;
+   const int list_mask = (int)a.list_cap - 1;
+   int lifo_peak = 0;
+   int lifo_count = 0, lifo_head = 0;
+   auto list_put = [&](int k, unsigned v) { list[(lifo_head + k) & list_mask] = v; };
+   auto list_get = [&](int k) { return __hip_atomic_load(list + ((lifo_head + k) & list_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
    const unsigned long long n = a.n_dev ? (unsigned long long)*a.n_dev : a.n;
    unsigned long long *const stats = a.stats;
    const unsigned long long clock_start = COUNT ? wall_clock64() : 0ULL;     /* 100 MHz */
+#ifdef RT_DEBUG_EXIT_HIST
+   const unsigned long long dbg_start = wall_clock64();
+#endif
 
    bool active = false;
    bool pend = false;                  /* OUT_CHAIN: finished, its bounce rays not spawned yet */
@@ -570,26 +591,27 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          bool okR = want_refl && slotR < a.cap, okT = want_refr && slotT < a.cap;
          unsigned long long oR = __ballot(okR), oT = __ballot(okT);
          unsigned nR = __popcll(oR), nT = __popcll(oT);
-         bool room = lifo_count + (int)(nR + nT + cS) <= RT_LIFO_CAP;
+         bool room = list != nullptr && lifo_count + (int)(nR + nT + cS) <= (int)a.list_cap;
          /* bounce rays below, the shadow item on top: the lights are done first, the reflection's subtree before the
           * refraction's, so the list grows with the depth of the forest and not with its size */
          if (okT) {
             store_qray(a.rays, slotT, mk3(b.to[0], b.to[1], b.to[2]), mk3(b.td[0], b.td[1], b.td[2]), -FLT_MAX, tag + 1);
             out.child_refr = (int)slotT;
-            if (room) lifo[lifo_count + __popcll(oT & below)] = slotT;
+            if (room) list_put(lifo_count + __popcll(oT & below), slotT);
          }
          if (okR) {
             store_qray(a.rays, slotR, mk3(b.ro[0], b.ro[1], b.ro[2]), mk3(b.rd[0], b.rd[1], b.rd[2]), -FLT_MAX, tag + 1);
             out.child_refl = (int)slotR;
-            if (room) lifo[lifo_count + nT + __popcll(oR & below)] = slotR;
+            if (room) list_put(lifo_count + nT + __popcll(oR & below), slotR);
          }
-         if (want_sh && room) lifo[lifo_count + nT + nR + __popcll(mS & below)] = RT_SHADOW_ITEM | idx;   /* light 0 of entry idx */
+         if (want_sh && room) list_put(lifo_count + nT + nR + __popcll(mS & below), RT_SHADOW_ITEM | idx);   /* light 0 of entry idx */
          if (room) lifo_count += (int)(nR + nT + cS);
+         lifo_peak = lifo_count > lifo_peak ? lifo_count : lifo_peak;
          if (lane == leader) {
             if (nR) stat_add(stats, ST_REFLECT, (unsigned long long)nR);
             if (nT) stat_add(stats, ST_REFRACT, (unsigned long long)nT);
             if (nR + nT != cR + cT) stat_add(stats, ST_OVERFLOW, 1ULL);      /* the queue is full: the host retries with a larger one */
-            if (!room) stat_add(stats, ST_ABORTED, 1ULL);
+            if (!room) stat_add(stats, ST_LIST_OVERFLOW, 1ULL);              /* the list is full: the host retries with longer ones */
          }
       }
       if (pend) *reinterpret_cast<float4 *>(a.recs + idx) = make_float4(out.refl, out.alpha, __int_as_float(out.child_refl), __int_as_float(out.child_refr));
@@ -623,7 +645,12 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          }
          unsigned item = 0;
          bool own = !active && rank < take;
-         if (own) item = lifo[lifo_count - 1 - rank];
+         /* Newest first keeps the list short (a bounce tree is walked depth first), but on its own it lets the oldest
+          * entries wait as long as newer ones keep arriving -- whole subtrees then start only when the queue has
+          * run dry and stretch the end of the launch.  So a few lanes of every refill take the oldest entries. */
+         int from_old = take < a.take_oldest ? take : a.take_oldest;
+         if (own) item = rank < from_old ? list_get(rank) : list_get(lifo_count - 1 - (rank - from_old));
+         lifo_head = (lifo_head + from_old) & list_mask;
          lifo_count -= take;
          bool put_back = false;
          if (!active) {
@@ -659,7 +686,15 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                bool have = false;
                unsigned long long my = 0;
                if (own) { my = item; have = true; }
-               else if (need > 0) { my = base + (unsigned long long)(rank - take); have = my < n; }
+               else if (need > 0) {
+                  my = base + (unsigned long long)(rank - take); have = my < n;
+                  if (have && OUT == OUT_CHAIN && a.tile_order) {
+                     /* the k-th tile to be started is tile_order[k] of this launch's tiles; where a sample's results
+                      * are stored does not change */
+                     unsigned f = (unsigned)my, k = f / a.per_tile;
+                     my = (unsigned long long)a.tile_order[k] * a.per_tile + (f - k * a.per_tile);
+                  }
+               }
                if (have) {
                   QRay q;
                   if (own) q = load_qray_written(a.rays, my);
@@ -696,8 +731,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             unsigned long long mP = __ballot(put_back);
             if (mP) {
                /* at most as many go back as were taken, so there is room */
-               if (put_back) lifo[lifo_count + __popcll(mP & below)] = item;
+               if (put_back) list_put(lifo_count + __popcll(mP & below), item);
                lifo_count += __popcll(mP);
+               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             }
          }
          m_active = __ballot(active);
@@ -771,7 +807,15 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          }
       }
    }
+#ifdef RT_DEBUG_EXIT_HIST
+   if (lane == 0) {
+      unsigned long long dt = wall_clock64() - dbg_start;
+      unsigned bin = (unsigned)(dt / 25000ULL); if (bin > 47) bin = 47;
+      stat_add(stats, ST_HIST + (int)bin, 1ULL);
+   }
+#endif
    if (OUT == OUT_CHAIN) {
+      if (lane == 0 && lifo_peak) atomicMax(&stats[ST_MAX_LIST * RT_STAT_REPL], (unsigned long long)lifo_peak);
       unsigned long long m1 = __ballot(n_traced != 0), m2 = __ballot(n_skipped != 0);
       if (m1) stat_add(stats, ST_SHADOW_TRACED, (unsigned long long)n_traced);
       if (m2) stat_add(stats, ST_SHADOW_SKIPPED, (unsigned long long)n_skipped);
@@ -951,13 +995,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue
  * with vec3(0) for a ray that was not spawned or hit nothing.  One thread walks one tree (at most
  * 2^RT_MAX_RECURSE - 1 nodes, usually a short chain) with an explicit stack of one frame per level, so every
  * node is evaluated once, by one thread, in the reference's operand order: no atomics, no races. */
-__global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs, const float *totals, long long n_primary, float *rgb)
+__global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs, const float *totals, long long n_primary, float *rgb,
+                                                           unsigned *tile_cost, unsigned per_tile)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-   if (i >= n_primary) return;
+   const bool live = i < n_primary;
    int node[RT_MAX_RECURSE], stage[RT_MAX_RECURSE];
    float rx[RT_MAX_RECURSE], ry[RT_MAX_RECURSE], rz[RT_MAX_RECURSE];
-   int sp = 0;
+   int sp = live ? 0 : -1;
+   unsigned deepest = 0;        /* levels below the primary that its bounce tree reaches */
    node[0] = (int)i; stage[0] = 0;
    F3 ret = mk3(0.0f, 0.0f, 0.0f);
    while (sp >= 0) {
@@ -978,10 +1024,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs,
       F3 total = mk3(totals[3 * k], totals[3 * k + 1], totals[3 * k + 2]);
       F3 refl = mk3(rx[sp], ry[sp], rz[sp]);
       ret = total * (1.0f - rr.x - rr.y) + rr.x * refl + rr.y * ret;
+      deepest = (unsigned)sp > deepest ? (unsigned)sp : deepest;
       sp--;
    }
    /* rayTrace's clamp (kernel.cu:537-539); NaN passes through clamp unchanged (Util.h:28-30) */
-   rgb[3 * i] = clamp01(ret.x); rgb[3 * i + 1] = clamp01(ret.y); rgb[3 * i + 2] = clamp01(ret.z);
+   if (live) { rgb[3 * i] = clamp01(ret.x); rgb[3 * i + 1] = clamp01(ret.y); rgb[3 * i + 2] = clamp01(ret.z); }
+   if (tile_cost) {
+      /* How long the dependent chains of this tile's bounce trees are, for the order in which the next frame
+       * starts its tiles.  A wave's 64 primaries lie in one tile (a tile's sample count is a multiple of 64):
+       * the sum of their depths, so that a tile of many deep trees ranks above one with a single deep tree. */
+      for (int o = 32; o > 0; o >>= 1) deepest += __shfl_xor(deepest, o);
+      if ((threadIdx.x & 63) == 0 && live && deepest) atomicAdd(&tile_cost[(unsigned)(i / per_tile)], deepest);
+   }
 }
 
 __device__ __forceinline__ unsigned char to_byte(float v)
@@ -1087,6 +1141,15 @@ struct rt_scene {
    unsigned long long *d_stats;
    unsigned long long *h_stats;  /* pinned */
    float node_factor;       /* queue entries per primary ray the chain kernel gets room for; grows when a frame overflows */
+   unsigned *d_lists;       /* the waves' lists of spawned rays (k_trace): list_waves rings of list_cap entries */
+   unsigned list_cap, list_waves;
+   /* Tiles are started costliest first, by the previous frame's depth of the bounce trees per tile: the waves that
+    * pick up the last primaries of a launch then hold short chains, and the launch does not end on a few long ones. */
+   unsigned *d_tile_cost, *h_tile_cost;   /* h_: pinned */
+   int *d_tile_order, *h_tile_order;      /* h_: pinned */
+   long long order_cap;                   /* tiles the four arrays have room for */
+   long long order_key[6];                /* width, height, samples, tile_first, tile_stride, tiles of the frame the order is for */
+   bool order_valid;
    /* Two internal streams: `chain` traces the bounce trees of one chunk of tiles after the other, `side` runs
     * the shadow rays, light sums, combine and resolve of the chunks the chain is through with, so that the
     * tail of each traversal launch (its longest rays) overlaps the bulk of the other stream's. */
@@ -1119,6 +1182,11 @@ extern "C" void rt_scene_destroy(rt_scene *s)
    if (s->d_ctr) (void)hipFree(s->d_ctr);
    if (s->d_stats) (void)hipFree(s->d_stats);
    if (s->h_stats) (void)hipHostFree(s->h_stats);
+   if (s->d_lists) (void)hipFree(s->d_lists);
+   if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
+   if (s->d_tile_order) (void)hipFree(s->d_tile_order);
+   if (s->h_tile_cost) (void)hipHostFree(s->h_tile_cost);
+   if (s->h_tile_order) (void)hipHostFree(s->h_tile_order);
    if (s->streams_ok) {
       (void)hipStreamDestroy(s->chain); (void)hipStreamDestroy(s->side);
       for (int l = 0; l < RT_RING; l++) { (void)hipEventDestroy(s->ev_chain[l]); (void)hipEventDestroy(s->ev_side[l]); }
@@ -1138,6 +1206,8 @@ extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
    memset(&s->d, 0, sizeof s->d);
    s->device = -1; s->flags = 0; s->streams_ok = false; s->ms_build_device = 0.0f;
    s->dev_blob = nullptr; s->dev_bytes = 0; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
+   s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false;
+   s->d_lists = nullptr; s->list_cap = RT_LIST_CAP_FIRST; s->list_waves = 0;
    s->camera = desc->camera; s->has_camera = desc->has_camera; s->ms_upload = 0;
    auto t0 = std::chrono::steady_clock::now();
    int st = rt_flatten_scene(desc, &s->host);
@@ -1161,6 +1231,8 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    memset(&s->host, 0, sizeof s->host);
    s->device = device; s->flags = flags; s->streams_ok = false; s->ms_build_device = 0.0f;
    s->dev_blob = nullptr; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
+   s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false;
+   s->d_lists = nullptr; s->list_cap = RT_LIST_CAP_FIRST; s->list_waves = 0;
    s->camera = desc->camera; s->has_camera = desc->has_camera;
 
    auto t0 = std::chrono::steady_clock::now();
@@ -1334,11 +1406,13 @@ static long long max_batch_slots()
    return v > 0 ? v : (long long)(1 << 24);
 }
 
+static int g_trace_blocks = 0;
+
 static int trace_lds_bytes(const rt_scene *s, size_t *out)
 {
-   /* the stack holds at most one deferred sibling per internal level; behind it, one list of spawned rays per wave */
+   /* the stack holds at most one deferred sibling per internal level */
    int depth = s->host.tree_depth > 0 ? s->host.tree_depth : 1;
-   size_t lds_bytes = sizeof(StackEntry) * (size_t)RT_BLOCK * (size_t)depth + (RT_BLOCK / 64) * RT_LIFO_CAP * sizeof(unsigned);
+   size_t lds_bytes = sizeof(StackEntry) * (size_t)RT_BLOCK * (size_t)depth;
    if (lds_bytes > 160 * 1024) { rt_set_error("BVH depth %d needs %zu bytes of LDS", s->host.tree_depth, lds_bytes); return RT_ERR_TOO_LARGE; }
    if (lds_bytes > 64 * 1024) {
       HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_HIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1350,12 +1424,10 @@ static int trace_lds_bytes(const rt_scene *s, size_t *out)
    return RT_OK;
 }
 
-static int g_trace_blocks = 0;
 
 /* persistent traversal launch: enough blocks to fill the chip a few times over; every wave pulls rays until
  * the queue is dry.  `n_hint` bounds the number of rays (it sizes the grid when the count lives on the device). */
-static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs a, unsigned long long n_hint, size_t lds_bytes,
-                         hipStream_t stream)
+static int trace_blocks_max(const rt_scene *s)
 {
    if (g_trace_blocks == 0) {
       const char *e = getenv("RT_TRACE_BLOCKS");
@@ -1364,6 +1436,25 @@ static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs 
       if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
       g_trace_blocks = e && atoi(e) > 0 ? atoi(e) : cus * 4;
    }
+   return g_trace_blocks;
+}
+
+/* room for the lists of every wave a launch can have */
+static int ensure_lists(rt_scene *s)
+{
+   const unsigned waves = (unsigned)trace_blocks_max(s) * (RT_BLOCK / 64);
+   if (s->d_lists && s->list_waves == waves) return RT_OK;
+   if (s->d_lists) { (void)hipFree(s->d_lists); s->d_lists = nullptr; }
+   hipError_t e = hipMalloc((void **)&s->d_lists, sizeof(unsigned) * (size_t)waves * s->list_cap);
+   if (e != hipSuccess) { rt_set_error("hipMalloc of the spawn lists (%u x %u entries) failed: %s", waves, s->list_cap, hipGetErrorString(e)); return RT_ERR_HIP; }
+   s->list_waves = waves;
+   return RT_OK;
+}
+
+static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs a, unsigned long long n_hint, size_t lds_bytes,
+                         hipStream_t stream)
+{
+   (void)trace_blocks_max(s);
    unsigned long long want = (n_hint + RT_BLOCK - 1) / RT_BLOCK;
    unsigned blocks = (unsigned)(want < (unsigned long long)g_trace_blocks ? want : (unsigned long long)g_trace_blocks);
    if (blocks == 0) return;
@@ -1373,6 +1464,9 @@ static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs 
       if (!refill) { const char *e = getenv("RT_REFILL_IDLE"); refill = e && atoi(e) > 0 ? atoi(e) : RT_REFILL_IDLE; }
       if (!burst) { const char *e = getenv("RT_NODE_BURST"); burst = e && atoi(e) > 0 ? atoi(e) : RT_NODE_BURST; }
       a.refill_idle = refill; a.node_burst = burst;
+      static int oldest = -1;
+      if (oldest < 0) { const char *e = getenv("RT_TAKE_OLDEST"); oldest = e ? atoi(e) : RT_TAKE_OLDEST; }
+      a.take_oldest = oldest;
    }
    a.stats = s->d_stats;
 #define RT_LAUNCH_TRACE(O, C) hipLaunchKernelGGL((k_trace<O, C>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, a)
@@ -1475,7 +1569,27 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       const size_t o_flags = carve(n_feelers);
       const size_t slice = used;
       if (slice * (size_t)ring > s->arena.cap) { int rc = arena_reserve(s->arena, slice * (size_t)ring); if (rc != RT_OK) return rc; }
+      { int rc = ensure_lists(s); if (rc != RT_OK) return rc; }
 #define AT(T, r, off) ((T *)(s->arena.base + (size_t)(r) * slice + (off)))
+
+      /* tile start order: only for a frame that is one launch, and from a frame of the same geometry */
+      const long long key[6] = {p->width, p->height, p->sample_count, tile_first, tile_stride, n_sel};
+      static int use_order = -1;
+      if (use_order < 0) { const char *e = getenv("RT_TILE_ORDER"); use_order = e ? atoi(e) : 1; }
+      const bool track_cost = use_order && n_chunks == 1 && view != VIEW_PRIMARY && max_rec > 1 && per_tile % 64 == 0;
+      if (track_cost && n_sel > s->order_cap) {
+         if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
+         if (s->d_tile_order) (void)hipFree(s->d_tile_order);
+         if (s->h_tile_cost) (void)hipHostFree(s->h_tile_cost);
+         if (s->h_tile_order) (void)hipHostFree(s->h_tile_order);
+         s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false;
+         const size_t bytes = sizeof(unsigned) * (size_t)n_sel;
+         HIP_TRY(hipMalloc((void **)&s->d_tile_cost, bytes)); HIP_TRY(hipMalloc((void **)&s->d_tile_order, bytes));
+         HIP_TRY(hipHostMalloc((void **)&s->h_tile_cost, bytes, hipHostMallocDefault));
+         HIP_TRY(hipHostMalloc((void **)&s->h_tile_order, bytes, hipHostMallocDefault));
+         s->order_cap = n_sel;
+      }
+      const bool have_order = track_cost && s->order_valid && memcmp(key, s->order_key, sizeof key) == 0;
 
       /* the caller's stream brackets the frame; the work itself runs on the two internal streams */
       EventPool ev;
@@ -1506,6 +1620,14 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             a.rays = queue; a.n = (unsigned long long)np; a.hits = hits; a.next = ctr.next_chain;
             a.flags = AT(unsigned char, r, o_flags);
             a.recs = recs; a.tail = ctr.tail; a.cap = cap; a.max_rec = max_rec; a.cam = cam; a.g = g;
+            a.per_tile = (unsigned)per_tile;
+            a.lists = s->d_lists; a.list_cap = s->list_cap;
+            if (!a.lists || a.list_cap == 0 || (a.list_cap & (a.list_cap - 1)) != 0) { rt_set_error("internal: spawn lists not set up"); return RT_ERR_HIP; }
+            if (have_order) {
+               HIP_TRY(hipMemcpyAsync(s->d_tile_order, s->h_tile_order, sizeof(int) * (size_t)n_sel, hipMemcpyHostToDevice, S));
+               a.tile_order = s->d_tile_order;
+            }
+            if (track_cost) HIP_TRY(hipMemsetAsync(s->d_tile_cost, 0, sizeof(unsigned) * (size_t)n_sel, S));
             Timer &tm = ev.begin(S, &st.ms_trace);
             launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, S);
             ev.end(tm, S); st.launches_trace++;
@@ -1523,8 +1645,10 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             ev.end(tm, S);
             Timer &tc = ev.begin(S, &st.ms_combine);
             hipLaunchKernelGGL(k_combine_tree, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, (const SpawnRec *)recs,
-                               (const float *)AT(float, r, o_totals), np, AT(float, r, o_rgb));
+                               (const float *)AT(float, r, o_totals), np, AT(float, r, o_rgb),
+                               track_cost ? s->d_tile_cost : (unsigned *)nullptr, (unsigned)per_tile);
             ev.end(tc, S);
+            if (track_cost) HIP_TRY(hipMemcpyAsync(s->h_tile_cost, s->d_tile_cost, sizeof(unsigned) * (size_t)n_sel, hipMemcpyDeviceToHost, S));
          }
          if (view == VIEW_FRAME) {
             Timer &tr = ev.begin(S, &st.ms_resolve);
@@ -1549,9 +1673,15 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       HIP_TRY(hipStreamSynchronize(H));
       HIP_TRY(hipGetLastError());
       ev.collect();
-      if (sum_stat(s->h_stats, ST_ABORTED) != 0) { rt_set_error("traversal aborted: step cap or spawn list limit reached (corrupt scene?)"); return RT_ERR_HIP; }
+      if (sum_stat(s->h_stats, ST_ABORTED) != 0) { rt_set_error("traversal aborted: step cap reached (corrupt scene?)"); return RT_ERR_HIP; }
       /* queue entries per primary the largest chunk wanted, in sixteenths */
       double wanted = (double)s->h_stats[ST_NODES_PER_PRIMARY_X16 * RT_STAT_REPL] / 16.0;
+      if (sum_stat(s->h_stats, ST_LIST_OVERFLOW) != 0) {
+         /* a wave's list of spawned rays was full and some were dropped: longer lists, and the frame again */
+         if (attempt >= 8 || s->list_cap >= RT_LIST_CAP_MAX) { rt_set_error("spawn list overflow persists at %u entries per wave", s->list_cap); return RT_ERR_TOO_LARGE; }
+         s->list_cap *= 2; s->list_waves = 0;
+         continue;
+      }
       if (sum_stat(s->h_stats, ST_OVERFLOW) != 0) {
          if (attempt >= 8) { rt_set_error("ray queue overflow persists"); return RT_ERR_TOO_LARGE; }
          double grown = wanted * 1.25 > 2.0 * F ? wanted * 1.25 : 2.0 * F;
@@ -1559,6 +1689,17 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          continue;                              /* some bounce rays were dropped: render the frame again */
       }
       if (max_rec > 1 && wanted * 1.1 > F) s->node_factor = (float)(wanted * 1.25 < 64.0 ? wanted * 1.25 : 64.0);
+      if (track_cost) {
+         /* costliest first, in 17 classes (none, 1, 2-3, 4-7, ...); tiles of a class stay in image order, so
+          * neighbouring waves still work on neighbouring tiles */
+         long long start[18] = {0};
+         auto cls = [](unsigned c) { int b = 0; while (c) { b++; c >>= 1; } return b > 16 ? 16 : b; };
+         for (long long k = 0; k < n_sel; k++) start[16 - cls(s->h_tile_cost[k]) + 1]++;
+         for (int b = 0; b < 17; b++) start[b + 1] += start[b];
+         for (long long k = 0; k < n_sel; k++) s->h_tile_order[start[16 - cls(s->h_tile_cost[k])]++] = (int)k;
+         memcpy(s->order_key, key, sizeof key);
+         s->order_valid = true;
+      }
       break;
    }
    st.rays_primary = sum_stat(s->h_stats, ST_PRIMARY);
@@ -1574,7 +1715,13 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    st.tie_events_shadow = sum_stat(s->h_stats, ST_TIES_SHADOW);
    st.wave_node_steps = sum_stat(s->h_stats, ST_WAVE_NODE_STEPS); st.wave_leaf_steps = sum_stat(s->h_stats, ST_WAVE_LEAF_STEPS);
    st.max_ray_steps = s->h_stats[ST_MAX_RAY_STEPS * RT_STAT_REPL];
+   st.max_spawn_list = s->h_stats[ST_MAX_LIST * RT_STAT_REPL];
    st.attempts = attempts;
+#ifdef RT_DEBUG_EXIT_HIST
+   fprintf(stderr, "wave exits per 0.25 ms:");
+   for (int b = 0; b < 48; b++) fprintf(stderr, " %llu", (unsigned long long)sum_stat(s->h_stats, ST_HIST + b));
+   fprintf(stderr, "\n");
+#endif
    if (count && sum_stat(s->h_stats, ST_WAVES) > 0 && st.launches_trace == 1) {
       double first = (double)(~s->h_stats[ST_CLOCK_FIRST_START * RT_STAT_REPL]);
       double waves = (double)sum_stat(s->h_stats, ST_WAVES);

@@ -387,34 +387,6 @@ extern "C" void rt_set_error(const char *fmt, ...)
 }
 extern "C" const char *rt_last_error(void) { return g_error; }
 
-/* The device copy of the tree: the first `k_top` internal nodes breadth-first from the root (levels closest to the
- * root first -- these are the records the traversal kernel keeps in LDS), the rest in their host order.  Only
- * the numbering changes; `out` has room for n records and out[0] is the root. */
-extern "C" void rt_order_nodes_for_device(const rt_bvh_node *in, int n, int root, int k_top, rt_bvh_node *out)
-{
-   if (n <= 0) return;
-   if (root < 0 || root >= n) { memcpy(out, in, sizeof(rt_bvh_node) * (size_t)n); return; }
-   std::vector<int32_t> map((size_t)n, -1), order;
-   order.reserve((size_t)n);
-   order.push_back(root); map[(size_t)root] = 0;
-   for (size_t head = 0; head < order.size() && (int)order.size() < k_top; head++) {
-      const rt_bvh_node &nd = in[order[head]];
-      const int32_t ch[2] = {nd.left, nd.right};
-      for (int k = 0; k < 2; k++)
-         if (ch[k] >= 0 && ch[k] < n && map[(size_t)ch[k]] < 0 && (int)order.size() < k_top) {
-            map[(size_t)ch[k]] = (int32_t)order.size(); order.push_back(ch[k]);
-         }
-   }
-   for (int k = 0; k < n; k++)
-      if (map[(size_t)k] < 0) { map[(size_t)k] = (int32_t)order.size(); order.push_back(k); }
-   for (int k = 0; k < n; k++) {
-      rt_bvh_node rec = in[order[(size_t)k]];
-      if (rec.left >= 0 && rec.left < n) rec.left = map[(size_t)rec.left];
-      if (rec.right >= 0 && rec.right < n) rec.right = map[(size_t)rec.right];
-      out[k] = rec;
-   }
-}
-
 extern "C" int rt_flatten_scene(const rt_scene_desc *d, rt_flat_scene *out) { return rt_flatten_scene_ex(d, 0, out); }
 
 extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_scene *out)

@@ -44,8 +44,8 @@ def test_struct_sizes_match_header():
     assert C.sizeof(abi.Camera) == 48
     assert C.sizeof(abi.RenderParams) == 40
     assert C.sizeof(abi.SceneInfo) == 56
-    # rt_stats: 8 u64, 7 floats + 2 i32 (36 bytes -> padded to 40), 9 u64
-    assert C.sizeof(abi.Stats) == 8 * 8 + 40 + 9 * 8
+    # rt_stats: 8 u64, 7 floats + 2 i32 (36 bytes -> padded to 40), 10 u64
+    assert C.sizeof(abi.Stats) == 8 * 8 + 40 + 10 * 8
 
 
 def test_missing_library_fails_loudly(tmp_path):
