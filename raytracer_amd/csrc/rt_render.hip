@@ -311,8 +311,8 @@ __device__ __forceinline__ Ray camera_ray(const DCamera &cam, const DGrid &g, in
  *
  * OUT_HIT    a plain queue of rays: writes the closest hit of ray i to hits[i] (toBeat early-out honoured).
  * OUT_CHAIN  the whole shade forest of the first n rays (the primaries) in one launch.  When a ray has found
- *            its hit, three kinds of follow-up work go onto a per-wave last-in-first-out list in LDS, which
- *            the wave's idle lanes drain before they fetch new primaries:
+ *            its hit, three kinds of follow-up work go onto a per-wave list (a ring in global memory), which
+ *            the wave's idle lanes drain, oldest entry first, before they fetch new primaries:
  *              - its reflection and refraction rays (getReflection / getRefraction, kernel.cu:209-276,
  *                guarded as in kernel.cu:361-371), appended to the same queue behind the primaries (one
  *                atomic per wave for the indices; valid = depth level + 1);
@@ -321,6 +321,11 @@ __device__ __forceinline__ Ray camera_ray(const DCamera &cam, const DGrid &g, in
  *                lane.  The feeler's own-surface test (kernel.cu:351) is an ordinary leaf step: the lane
  *                starts at the leaf of the shaded primitive in MODE_SETUP and moves to the root with the
  *                result as its toBeat.
+ *            Oldest first, because newest first lets an old entry (and the subtree behind it) wait until the
+ *            primaries have run dry; the price is a list that grows with the breadth of the forest, which is
+ *            why it lives in global memory and a frame that overflows it is rendered again with longer lists.
+ *            Primaries are fetched tile by tile in the order the host passes (tiles whose bounce trees were
+ *            deepest in the previous frame first), so that the last primaries of a launch start short chains.
  *            No data is handed between waves, so there is nothing to wait for and every wave's exit is its
  *            own: primaries dry, list empty, lanes idle. */
 enum { OUT_HIT = 0, OUT_CHAIN = 2 };
@@ -453,10 +458,10 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
     * CU's vector cache (the reader is another lane of the same wave, some refills later). */
    unsigned *const list = a.lists ? a.lists + (size_t)(blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * a.list_cap : nullptr;
    const int list_mask = (int)a.list_cap - 1;
-   int lifo_peak = 0;
-   int lifo_count = 0, lifo_head = 0;
-   auto list_put = [&](int k, unsigned v) { list[(lifo_head + k) & list_mask] = v; };
-   auto list_get = [&](int k) { return __hip_atomic_load(list + ((lifo_head + k) & list_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+   int list_peak = 0;
+   int list_count = 0, list_head = 0;
+   auto list_put = [&](int k, unsigned v) { list[(list_head + k) & list_mask] = v; };
+   auto list_get = [&](int k) { return __hip_atomic_load(list + ((list_head + k) & list_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
    const unsigned long long n = a.n_dev ? (unsigned long long)*a.n_dev : a.n;
    unsigned long long *const stats = a.stats;
    const unsigned long long clock_start = COUNT ? wall_clock64() : 0ULL;     /* 100 MHz */
@@ -591,22 +596,21 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          bool okR = want_refl && slotR < a.cap, okT = want_refr && slotT < a.cap;
          unsigned long long oR = __ballot(okR), oT = __ballot(okT);
          unsigned nR = __popcll(oR), nT = __popcll(oT);
-         bool room = list != nullptr && lifo_count + (int)(nR + nT + cS) <= (int)a.list_cap;
-         /* bounce rays below, the shadow item on top: the lights are done first, the reflection's subtree before the
-          * refraction's, so the list grows with the depth of the forest and not with its size */
+         bool room = list != nullptr && list_count + (int)(nR + nT + cS) <= (int)a.list_cap;
+         /* in list order: the refraction ray, the reflection ray, the shadow item */
          if (okT) {
             store_qray(a.rays, slotT, mk3(b.to[0], b.to[1], b.to[2]), mk3(b.td[0], b.td[1], b.td[2]), -FLT_MAX, tag + 1);
             out.child_refr = (int)slotT;
-            if (room) list_put(lifo_count + __popcll(oT & below), slotT);
+            if (room) list_put(list_count + __popcll(oT & below), slotT);
          }
          if (okR) {
             store_qray(a.rays, slotR, mk3(b.ro[0], b.ro[1], b.ro[2]), mk3(b.rd[0], b.rd[1], b.rd[2]), -FLT_MAX, tag + 1);
             out.child_refl = (int)slotR;
-            if (room) list_put(lifo_count + nT + __popcll(oR & below), slotR);
+            if (room) list_put(list_count + nT + __popcll(oR & below), slotR);
          }
-         if (want_sh && room) list_put(lifo_count + nT + nR + __popcll(mS & below), RT_SHADOW_ITEM | idx);   /* light 0 of entry idx */
-         if (room) lifo_count += (int)(nR + nT + cS);
-         lifo_peak = lifo_count > lifo_peak ? lifo_count : lifo_peak;
+         if (want_sh && room) list_put(list_count + nT + nR + __popcll(mS & below), RT_SHADOW_ITEM | idx);   /* light 0 of entry idx */
+         if (room) list_count += (int)(nR + nT + cS);
+         list_peak = list_count > list_peak ? list_count : list_peak;
          if (lane == leader) {
             if (nR) stat_add(stats, ST_REFLECT, (unsigned long long)nR);
             if (nT) stat_add(stats, ST_REFRACT, (unsigned long long)nT);
@@ -629,12 +633,12 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       unsigned long long m_active = __ballot(active);
       int n_idle = 64 - __popcll(m_active);
       bool any_pend = OUT == OUT_CHAIN && __ballot(pend) != 0;
-      if ((n_idle >= a.refill_idle || m_active == 0) && (!exhausted || lifo_count > 0 || any_pend)) {
+      if ((n_idle >= a.refill_idle || m_active == 0) && (!exhausted || list_count > 0 || any_pend)) {
          if (any_pend) spawn_stage();
          unsigned long long m_idle = ~m_active;
          int rank = __popcll(m_idle & below);
          int take = 0;
-         if (OUT == OUT_CHAIN) take = n_idle < lifo_count ? n_idle : lifo_count;
+         if (OUT == OUT_CHAIN) take = n_idle < list_count ? n_idle : list_count;
          int need = exhausted ? 0 : n_idle - take;
          unsigned long long base = 0;
          if (need > 0) {
@@ -645,13 +649,13 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          }
          unsigned item = 0;
          bool own = !active && rank < take;
-         /* Newest first keeps the list short (a bounce tree is walked depth first), but on its own it lets the oldest
-          * entries wait as long as newer ones keep arriving -- whole subtrees then start only when the queue has
-          * run dry and stretch the end of the launch.  So a few lanes of every refill take the oldest entries. */
+         /* The oldest entries go first (a.take_oldest = 64 lanes' worth): with newest first an old entry waits for
+          * as long as newer ones keep arriving, and the subtree behind it starts only when the queue has run dry
+          * and stretches the end of the launch.  Fewer than 64 mixes the two orders (kept for experiments). */
          int from_old = take < a.take_oldest ? take : a.take_oldest;
-         if (own) item = rank < from_old ? list_get(rank) : list_get(lifo_count - 1 - (rank - from_old));
-         lifo_head = (lifo_head + from_old) & list_mask;
-         lifo_count -= take;
+         if (own) item = rank < from_old ? list_get(rank) : list_get(list_count - 1 - (rank - from_old));
+         list_head = (list_head + from_old) & list_mask;
+         list_count -= take;
          bool put_back = false;
          if (!active) {
             if (OUT == OUT_CHAIN && own && (item & RT_SHADOW_ITEM)) {
@@ -731,8 +735,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             unsigned long long mP = __ballot(put_back);
             if (mP) {
                /* at most as many go back as were taken, so there is room */
-               if (put_back) list_put(lifo_count + __popcll(mP & below), item);
-               lifo_count += __popcll(mP);
+               if (put_back) list_put(list_count + __popcll(mP & below), item);
+               list_count += __popcll(mP);
                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             }
          }
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          wave_lit = __ballot(active && !c.fast) != 0;
       }
       if (m_active == 0) {
-         if (exhausted && lifo_count == 0 && !(OUT == OUT_CHAIN && __ballot(pend) != 0)) break;
+         if (exhausted && list_count == 0 && !(OUT == OUT_CHAIN && __ballot(pend) != 0)) break;
          continue;
       }
       /* ---- node steps ---- */
@@ -815,7 +819,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    }
 #endif
    if (OUT == OUT_CHAIN) {
-      if (lane == 0 && lifo_peak) atomicMax(&stats[ST_MAX_LIST * RT_STAT_REPL], (unsigned long long)lifo_peak);
+      if (lane == 0 && list_peak) atomicMax(&stats[ST_MAX_LIST * RT_STAT_REPL], (unsigned long long)list_peak);
       unsigned long long m1 = __ballot(n_traced != 0), m2 = __ballot(n_skipped != 0);
       if (m1) stat_add(stats, ST_SHADOW_TRACED, (unsigned long long)n_traced);
       if (m2) stat_add(stats, ST_SHADOW_SKIPPED, (unsigned long long)n_skipped);
