@@ -213,7 +213,8 @@ def main():
                     "l2_peak": L2_PEAK_GBS, "frac_of_l2_peak": round(achieved / L2_PEAK_GBS, 4),
                     "note": "scene + BVH are 1.3 MB and stay in L2, so the algorithmic bytes (one 64-byte record per node "
                             "visit) are served by L2 and can exceed the HBM peak; measured HBM-side traffic is `traffic`. "
-                            "The kernel is bound by VALU issue (about 70 % busy) and dependent-fetch latency"}
+                            "What bounds the kernel is each wave's own dependent chain (about 130 instructions and one record "
+                            "fetch per traversal step) at the 4 waves per SIMD that 128 registers allow, not bandwidth"}
         if world == 1 and not args.no_cpu_baseline:
             baseline = cpu_baseline(sd, shading, jitter)
         if world == 1 and not args.no_fast_bvh:
