@@ -1170,6 +1170,18 @@ static unsigned long long sum_stat(const unsigned long long *h, int which)
    return t;
 }
 
+/* entries of a wave's spawn list to begin with; RT_LIST_CAP overrides it (rounded up to a power of two, at least 64):
+ * small values make frames overflow and exercise the retry */
+static unsigned first_list_cap()
+{
+   const char *e = getenv("RT_LIST_CAP");
+   long v = e ? atol(e) : 0;
+   if (v <= 0) return RT_LIST_CAP_FIRST;
+   unsigned c = 64;
+   while (c < (unsigned long)v && c < RT_LIST_CAP_MAX) c *= 2;
+   return c;
+}
+
 extern "C" int rt_device_count(void)
 {
    int n = 0;
@@ -1211,7 +1223,7 @@ extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
    s->device = -1; s->flags = 0; s->streams_ok = false; s->ms_build_device = 0.0f;
    s->dev_blob = nullptr; s->dev_bytes = 0; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
    s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false;
-   s->d_lists = nullptr; s->list_cap = RT_LIST_CAP_FIRST; s->list_waves = 0;
+   s->d_lists = nullptr; s->list_cap = first_list_cap(); s->list_waves = 0;
    s->camera = desc->camera; s->has_camera = desc->has_camera; s->ms_upload = 0;
    auto t0 = std::chrono::steady_clock::now();
    int st = rt_flatten_scene(desc, &s->host);
@@ -1236,7 +1248,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->device = device; s->flags = flags; s->streams_ok = false; s->ms_build_device = 0.0f;
    s->dev_blob = nullptr; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
    s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false;
-   s->d_lists = nullptr; s->list_cap = RT_LIST_CAP_FIRST; s->list_waves = 0;
+   s->d_lists = nullptr; s->list_cap = first_list_cap(); s->list_waves = 0;
    s->camera = desc->camera; s->has_camera = desc->has_camera;
 
    auto t0 = std::chrono::steady_clock::now();

@@ -64,6 +64,23 @@ def test_closed_glass_room_grows_whole_trees():
     assert st["rays_reflect"] + st["rays_refract"] > 8 * st["rays_primary"]
 
 
+def test_spawn_list_overflow_is_retried(monkeypatch):
+    """Lists that start far too short (64 entries per wave): the frame that overflows them is rendered again with
+    longer ones and comes out the same bytes as with the default lists; the lists keep their length afterwards."""
+    sd = synth.glassy(ra.SceneData.load(os.path.join(GOLDEN, "scenes", "cornell.npz")), everything=True)
+    with ra.Scene(sd) as sc:
+        want, st0 = sc.render(192, 144, 1)
+    monkeypatch.setenv("RT_LIST_CAP", "64")
+    with ra.Scene(sd) as sc:
+        got, st = sc.render(192, 144, 1)
+        again, st2 = sc.render(192, 144, 1)
+    assert st["attempts"] > 1 and st2["attempts"] == 1
+    assert st["max_spawn_list"] > 64
+    assert got.tobytes() == want.tobytes() and again.tobytes() == want.tobytes()
+    for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "shade_nodes"):
+        assert st[k] == st0[k], k
+
+
 def test_glassy_height_field():
     compare(synth.glassy(synth.terrain(60, 30, lights_per_side=2)), 256, 144)
 
