@@ -338,7 +338,7 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2 };
 #define RT_TAKE_OLDEST 64    /* lanes of a refill that take the oldest list entries: all of them */
 #define RT_LIST_CAP_FIRST 1024u   /* entries of a wave's list to begin with; doubled when a frame overflows it */
 #define RT_LIST_CAP_MAX 65536u
-#define RT_NODE_BURST 12    /* node steps between two leaf steps / refill checks */
+#define RT_NODE_BURST 16    /* node steps between two leaf steps / refill checks */
 
 struct TraceArgs {
    QRay *rays;                  /* the queue; OUT_CHAIN appends spawned rays behind the first n */
