@@ -56,6 +56,7 @@ struct DScene {
    const uchar4 *texels;
    int n_prims, n_planes, n_lights, root;
    int fast_ok;      /* every BVH bound is finite and below 2^40 in magnitude */
+   int any_xform;    /* some BVH primitive carries a transform */
 };
 
 struct DCamera {
@@ -147,7 +148,14 @@ __device__ __forceinline__ float prim_intersect(const DScene &sc, int prim, cons
 {
    PrimRec p = load_prim(sc.prims, prim);
    Ray r = wray;
-   if (p.m.y & RT_FLAG_XFORM) r = ray_transform(wray, load_xform(sc.xforms, prim));
+   if (sc.any_xform) {
+      /* the transform is fetched beside the record, not after the record's flag has arrived: two dependent
+       * fetches would double the latency of every leaf step of a scene of transformed spheres */
+      rt_dev_xform x = load_xform(sc.xforms, prim);
+      asm volatile("" : "+v"(x.r[0][0]), "+v"(x.r[0][1]), "+v"(x.r[0][2]), "+v"(x.r[0][3]), "+v"(x.r[1][0]), "+v"(x.r[1][1]),
+                        "+v"(x.r[1][2]), "+v"(x.r[1][3]), "+v"(x.r[2][0]), "+v"(x.r[2][1]), "+v"(x.r[2][2]), "+v"(x.r[2][3]));
+      if (p.m.y & RT_FLAG_XFORM) r = ray_transform(wray, x);
+   }
    if (p.m.x == RT_PRIM_SPHERE) {
       return sphere_hit(r, mk3(p.a.x, p.a.y, p.a.z), p.a.w);
    } else if (p.m.x == RT_PRIM_BOX) {
@@ -1295,6 +1303,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->d.tex_info = (const rt_dev_texinfo *)(b + off[7]); s->d.texels = (const uchar4 *)(b + off[8]);
    s->d.n_prims = h.n_prims; s->d.n_planes = h.n_planes; s->d.n_lights = h.n_lights; s->d.root = h.root;
    s->d.fast_ok = h.bounds_in_range;
+   s->d.any_xform = h.any_xform;
 
    if (hipMalloc((void **)&s->d_ctr, RT_RING * 8 * sizeof(unsigned long long)) != hipSuccess ||
        hipMalloc((void **)&s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long)) != hipSuccess ||
