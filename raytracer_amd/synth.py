@@ -60,3 +60,47 @@ def glassy(scene: SceneData, everything=False):
             m = arr["mod"]["mat"]
             m["clr"], m["alpha"], m["refl"], m["refr"], m["ior"] = 1.0, 0.8, 0.3, 1.0, 1.33
     return out
+
+
+def from_obj(path, pigment=(0.85, 0.8, 0.7)):
+    """The scene the reference's objToPov.py makes of a Wavefront .obj (objToPov.py:7-23, 86-114), with a solid
+    pigment where that script writes an image_map: one smooth_triangle per face from its first three corners
+    (`v`, `vn` and, when present, `vt` indices, 1-based; coordinates pass through the "%.6f" text of a .pov
+    file), finish ambient .2 diffuse .6 specular .4 roughness .05, camera <1,6,12> up <0,1,0> right <1.33,0,0>
+    looking at the origin, one white light at <30,10,30>."""
+    v, vn, vt, faces = [], [], [], []
+    six = lambda x: float("%.6f" % float(x))
+    with open(path, "r") as f:
+        for line in f:
+            w = line.split()
+            if not w:
+                continue
+            if w[0] == "v":
+                v.append([six(x) for x in w[1:4]])
+            elif w[0] == "vn":
+                vn.append([six(x) for x in w[1:4]])
+            elif w[0] == "vt":
+                vt.append([six(x) for x in w[1:3]])
+            elif w[0] == "f":
+                corners = [c.split("/") for c in w[1:4]]
+                faces.append([(int(c[0]) - 1, int(c[1]) - 1 if len(c) == 3 and c[1] else -1, int(c[-1]) - 1) for c in corners])
+    v, vn = np.asarray(v, np.float32), np.asarray(vn, np.float32)
+    vt = np.asarray(vt, np.float32).reshape(-1, 2)
+    fa = np.asarray(faces, np.int64)                                   # (n, 3 corners, (v, vt, vn))
+    tris = np.zeros(len(fa), abi.smooth_triangle_dtype)
+    for k, (pn, nn, tn) in enumerate((("p1", "n1", "vt1"), ("p2", "n2", "vt2"), ("p3", "n3", "vt3"))):
+        tris[pn], tris[nn] = v[fa[:, k, 0]], vn[fa[:, k, 2]]
+        if len(vt) and (fa[:, :, 1] >= 0).all():
+            tris[tn] = vt[fa[:, k, 1]]
+    mod = identity_modifier(len(fa))
+    mod["mat"]["clr"] = np.asarray(pigment, np.float32)
+    mod["mat"]["amb"], mod["mat"]["dif"], mod["mat"]["spec"], mod["mat"]["rough"] = 0.2, 0.6, 0.4, 0.05
+    tris["mod"] = mod
+    sd = SceneData()
+    sd.smooth_triangles = tris
+    lights = np.zeros(1, abi.light_dtype)
+    lights["pos"], lights["clr"] = (30.0, 10.0, 30.0), (1.0, 1.0, 1.0)
+    sd.lights = lights
+    sd.camera = {"pos": np.array([1, 6, 12], np.float32), "up": np.array([0, 1, 0], np.float32),
+                 "right": np.array([1.33, 0, 0], np.float32), "look_at": np.array([0, 0, 0], np.float32)}
+    return sd

@@ -25,7 +25,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import orclib  # noqa: E402
+import orclib
+from raytracer_amd import synth  # noqa: E402
 from raytracer_amd import abi  # noqa: E402
 
 REF = orclib.REFERENCE_DIR
@@ -62,6 +63,10 @@ def main():
             t["rgba"] = read_bmp(os.path.join(REF, "blitz.bmp"))
         sd.save(os.path.join(HERE, "scenes", name + ".npz"))
         manifest["scenes"][name] = sd.counts()
+    # bunny.obj by the rules of the reference's objToPov.py, with a solid pigment (raytracer_amd.synth.from_obj)
+    obj = synth.from_obj(os.path.join(REF, "bunny.obj"))
+    obj.save(os.path.join(HERE, "scenes", "bunny_obj.npz"))
+    manifest["scenes"]["bunny_obj"] = obj.counts()
     for name in TGAS:
         img = read_tga(os.path.join(REF, name + ".tga"))
         np.savez_compressed(os.path.join(HERE, "tga", name + ".npz"), rgb=img)

@@ -28,6 +28,8 @@ def run(label, sd, w, h, spp, shading, fast=False):
 bunny = ra.SceneData.load(os.path.join(G, "bunny.npz"))
 dragon = ra.SceneData.load(os.path.join(G, "dragon_large_tris.npz"))
 run("config 3 stand-in A (bunny, Cook-Torrance, 4 strata)", bunny, 1920, 1080, 4, abi.RT_COOK_TORRANCE)
+run("config 3 stand-in B (bunny.obj, smooth triangles, Cook-Torrance, 4 strata)", ra.SceneData.load(os.path.join(G, "bunny_obj.npz")),
+    1920, 1080, 4, abi.RT_COOK_TORRANCE)
 run("config 4 stand-in (glassy dragon, depth 6)", synth.glassy(dragon), 3840, 2160, 1, abi.RT_PHONG)
 run("iceBot 4K", ra.SceneData.load(os.path.join(G, "iceBot.npz")), 3840, 2160, 1, abi.RT_PHONG)
 if len(sys.argv) > 1:

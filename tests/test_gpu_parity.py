@@ -27,7 +27,7 @@ def load(name):
 SMALL = ["simple", "simple_reflect", "simple_reflect2", "simple_refract", "simple_spec", "simple_tri", "simple_cam",
          "recurse_simp", "recurse_simp2", "transforms", "box", "final1", "final2", "cornell", "valentine",
          "ugly_part", "evil"]
-MESH = ["bunny_small_tris", "bunny", "dragon_large_tris", "balls2", "iceBot"]
+MESH = ["bunny_small_tris", "bunny", "dragon_large_tris", "balls2", "iceBot", "bunny_obj"]
 
 
 def check_scene(name, w, h, shading=abi.RT_PHONG, samples=1, jitter=abi.RT_JITTER_NONE, seed=0, rgb_tol=RGB_TOL):

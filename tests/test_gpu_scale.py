@@ -88,3 +88,12 @@ def test_glassy_height_field():
 def test_cook_torrance_four_strata():
     sd = ra.SceneData.load(os.path.join(GOLDEN, "scenes", "bunny.npz"))
     compare(sd, 480, 270, samples=4, shading=abi.RT_COOK_TORRANCE, seed=5, rgb_tol=1e-3)
+
+
+def test_smooth_mesh_cook_torrance_four_strata():
+    """bunny.obj as 4 968 smooth triangles (the reference's objToPov.py rules; camera moved in so that the mesh fills
+    the frame): interpolated normals, Cook-Torrance, 2 x 2 strata -- the shape of the reference's headline frame."""
+    sd = ra.SceneData.load(os.path.join(GOLDEN, "scenes", "bunny_obj.npz"))
+    sd.camera = dict(sd.camera, pos=np.array([0.1, 0.7, 1.5], np.float32), look_at=np.array([-0.15, 0.35, 0.0], np.float32))
+    st = compare(sd, 128, 96, samples=4, shading=abi.RT_COOK_TORRANCE, rgb_tol=1e-3)
+    assert st["shade_nodes"] > 0.2 * st["rays_primary"]
