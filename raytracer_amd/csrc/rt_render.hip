@@ -15,7 +15,8 @@
  *                   PhongShader.h, CookTorranceShader.h; getColor with textures, kernel.cu:323-332)
  *   k_combine_tree  colour = total*(1-refl-alpha) + refl*reflected + alpha*refracted (kernel.cu:375-376) over
  *                   each primary's bounce tree, children first: the reference's expression tree with the same
- *                   operands in the same order, no float atomics
+ *                   operands in the same order, no float atomics; also notes how deep each tile's trees were,
+ *                   which orders the tiles of the next frame's k_trace (costliest first)
  *   k_resolve       s x s box filter to 8 bits (averageBufferColors, kernel.cu:545-570)
  *
  * Each ray walks the tree in the reference's visiting order (near child first with its `<=` rule, a deferred
