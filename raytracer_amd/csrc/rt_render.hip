@@ -1169,6 +1169,7 @@ struct rt_scene {
    hipStream_t chain, side;
    hipEvent_t ev_chain[RT_RING], ev_side[RT_RING], ev_begin, ev_end;
    bool streams_ok;
+   std::vector<hipEvent_t> timing_events;   /* spare events of the per-frame timers */
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1212,6 +1213,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
    if (s->d_tile_order) (void)hipFree(s->d_tile_order);
    if (s->h_tile_cost) (void)hipHostFree(s->h_tile_cost);
    if (s->h_tile_order) (void)hipHostFree(s->h_tile_order);
+   for (hipEvent_t e : s->timing_events) (void)hipEventDestroy(e);
    if (s->streams_ok) {
       (void)hipStreamDestroy(s->chain); (void)hipStreamDestroy(s->side);
       for (int l = 0; l < RT_RING; l++) { (void)hipEventDestroy(s->ev_chain[l]); (void)hipEventDestroy(s->ev_side[l]); }
@@ -1397,16 +1399,25 @@ struct Timer {
    float *acc = nullptr;
 };
 
+/* timing events of one frame; the events themselves are kept by the scene from frame to frame */
 struct EventPool {
+   std::vector<hipEvent_t> &spare;
    std::deque<Timer> timers;   /* a deque: begin() hands out references that must survive later begin()s */
+   explicit EventPool(std::vector<hipEvent_t> &cache) : spare(cache) {}
    ~EventPool()
    {
-      for (auto &t : timers) if (t.ok) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+      for (auto &t : timers) if (t.ok) { spare.push_back(t.a); spare.push_back(t.b); }
+   }
+   bool take(hipEvent_t *e)
+   {
+      if (!spare.empty()) { *e = spare.back(); spare.pop_back(); return true; }
+      return hipEventCreate(e) == hipSuccess;
    }
    Timer &begin(hipStream_t st, float *acc)
    {
       Timer t; t.acc = acc;
-      t.ok = hipEventCreate(&t.a) == hipSuccess && hipEventCreate(&t.b) == hipSuccess;
+      t.ok = take(&t.a);
+      if (t.ok && !take(&t.b)) { spare.push_back(t.a); t.ok = false; }
       if (t.ok) (void)hipEventRecord(t.a, st);
       timers.push_back(t);
       return timers.back();
@@ -1618,7 +1629,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       const bool have_order = track_cost && s->order_valid && memcmp(key, s->order_key, sizeof key) == 0;
 
       /* the caller's stream brackets the frame; the work itself runs on the two internal streams */
-      EventPool ev;
+      EventPool ev(s->timing_events);
       Timer &t_total = ev.begin(stream, &st.ms_total);
       HIP_TRY(hipEventRecord(s->ev_begin, stream));
       HIP_TRY(hipStreamWaitEvent(M, s->ev_begin, 0));
