@@ -970,6 +970,19 @@ __device__ __forceinline__ ShadePoint shade_point(const DScene &sc, const QRay *
    return sp;
 }
 
+/* start of a chunk: its counters to zero, the queue's tail behind the primaries, and (first chunk) the statistics;
+ * one launch instead of a memset each */
+__global__ __launch_bounds__(RT_BLOCK) void k_begin_chunk(unsigned long long *stats, int n_stats, unsigned long long *ctr, unsigned *tail,
+                                                          unsigned n_primary, unsigned *tile_cost, int n_cost)
+{
+   int i = (int)(blockIdx.x * RT_BLOCK + threadIdx.x);
+   if (stats && i < n_stats) stats[i] = 0ULL;
+   if (tile_cost && i < n_cost) tile_cost[i] = 0u;
+   if (i < 8) ctr[i] = 0ULL;
+   __syncthreads();
+   if (i == 0) *tail = n_primary;       /* tail is one of ctr's words: set after the zeroing, by the same block */
+}
+
 /* light: totalLight of every node, the loop of kernel.cu:347-358 with the shadow flags.  Thread 0 also notes
  * how many queue entries the chain kernel wanted per primary (in sixteenths) so the host can size the next frame. */
 __global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue, const Hit *hits, const unsigned char *flags,
@@ -1162,7 +1175,7 @@ struct rt_scene {
    int *d_tile_order, *h_tile_order;      /* h_: pinned */
    long long order_cap;                   /* tiles the four arrays have room for */
    long long order_key[6];                /* width, height, samples, tile_first, tile_stride, tiles of the frame the order is for */
-   bool order_valid;
+   bool order_valid, order_dirty;         /* dirty: h_tile_order differs from what d_tile_order holds */
    /* Two internal streams: `chain` traces the bounce trees of one chunk of tiles after the other, `side` runs
     * the shadow rays, light sums, combine and resolve of the chunks the chain is through with, so that the
     * tail of each traversal launch (its longest rays) overlaps the bulk of the other stream's. */
@@ -1233,7 +1246,7 @@ extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
    memset(&s->d, 0, sizeof s->d);
    s->device = -1; s->flags = 0; s->streams_ok = false; s->ms_build_device = 0.0f;
    s->dev_blob = nullptr; s->dev_bytes = 0; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
-   s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false;
+   s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false; s->order_dirty = true;
    s->d_lists = nullptr; s->list_cap = first_list_cap(); s->list_waves = 0;
    s->camera = desc->camera; s->has_camera = desc->has_camera; s->ms_upload = 0;
    auto t0 = std::chrono::steady_clock::now();
@@ -1258,7 +1271,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    memset(&s->host, 0, sizeof s->host);
    s->device = device; s->flags = flags; s->streams_ok = false; s->ms_build_device = 0.0f;
    s->dev_blob = nullptr; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
-   s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false;
+   s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false; s->order_dirty = true;
    s->d_lists = nullptr; s->list_cap = first_list_cap(); s->list_waves = 0;
    s->camera = desc->camera; s->has_camera = desc->has_camera;
 
@@ -1619,7 +1632,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          if (s->d_tile_order) (void)hipFree(s->d_tile_order);
          if (s->h_tile_cost) (void)hipHostFree(s->h_tile_cost);
          if (s->h_tile_order) (void)hipHostFree(s->h_tile_order);
-         s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false;
+         s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false; s->order_dirty = true;
          const size_t bytes = sizeof(unsigned) * (size_t)n_sel;
          HIP_TRY(hipMalloc((void **)&s->d_tile_cost, bytes)); HIP_TRY(hipMalloc((void **)&s->d_tile_order, bytes));
          HIP_TRY(hipHostMalloc((void **)&s->h_tile_cost, bytes, hipHostMallocDefault));
@@ -1633,7 +1646,6 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       Timer &t_total = ev.begin(stream, &st.ms_total);
       HIP_TRY(hipEventRecord(s->ev_begin, stream));
       HIP_TRY(hipStreamWaitEvent(M, s->ev_begin, 0));
-      HIP_TRY(hipMemsetAsync(s->d_stats, 0, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), M));
 
       HIP_TRY(hipEventRecord(s->ev_chain[0], M));                       /* the zeroed statistics */
       if (H != M) HIP_TRY(hipStreamWaitEvent(H, s->ev_chain[0], 0));
@@ -1650,9 +1662,12 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          SpawnRec *recs = AT(SpawnRec, r, o_recs);
 
          if (c >= ring) HIP_TRY(hipStreamWaitEvent(S, s->ev_side[r], 0));     /* the slice's previous chunk is done with it */
-         HIP_TRY(hipMemsetAsync(s->d_ctr + 8 * r, 0, 8 * sizeof(unsigned long long), S));
          {
-            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ctr.tail, (int)np, 1, S));     /* spawned rays are appended behind the primaries */
+            /* counters to zero, spawned rays appended behind the primaries, tile costs and (first chunk) statistics cleared */
+            const int n_stats = c == 0 ? ST_COUNT * RT_STAT_REPL : 0, n_cost = track_cost ? (int)n_sel : 0;
+            const int n_init = n_stats > n_cost ? (n_stats > 8 ? n_stats : 8) : (n_cost > 8 ? n_cost : 8);
+            hipLaunchKernelGGL(k_begin_chunk, dim3(grid_for(n_init)), dim3(RT_BLOCK), 0, S, c == 0 ? s->d_stats : (unsigned long long *)nullptr,
+                               n_stats, s->d_ctr + 8 * r, ctr.tail, (unsigned)np, track_cost ? s->d_tile_cost : (unsigned *)nullptr, n_cost);
             TraceArgs a; memset(&a, 0, sizeof a);
             a.rays = queue; a.n = (unsigned long long)np; a.hits = hits; a.next = ctr.next_chain;
             a.flags = AT(unsigned char, r, o_flags);
@@ -1661,10 +1676,12 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             a.lists = s->d_lists; a.list_cap = s->list_cap;
             if (!a.lists || a.list_cap == 0 || (a.list_cap & (a.list_cap - 1)) != 0) { rt_set_error("internal: spawn lists not set up"); return RT_ERR_HIP; }
             if (have_order) {
-               HIP_TRY(hipMemcpyAsync(s->d_tile_order, s->h_tile_order, sizeof(int) * (size_t)n_sel, hipMemcpyHostToDevice, S));
+               if (s->order_dirty) {
+                  HIP_TRY(hipMemcpyAsync(s->d_tile_order, s->h_tile_order, sizeof(int) * (size_t)n_sel, hipMemcpyHostToDevice, S));
+                  s->order_dirty = false;
+               }
                a.tile_order = s->d_tile_order;
             }
-            if (track_cost) HIP_TRY(hipMemsetAsync(s->d_tile_cost, 0, sizeof(unsigned) * (size_t)n_sel, S));
             Timer &tm = ev.begin(S, &st.ms_trace);
             launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, S);
             ev.end(tm, S); st.launches_trace++;
@@ -1733,7 +1750,14 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          auto cls = [](unsigned c) { int b = 0; while (c) { b++; c >>= 1; } return b > 16 ? 16 : b; };
          for (long long k = 0; k < n_sel; k++) start[16 - cls(s->h_tile_cost[k]) + 1]++;
          for (int b = 0; b < 17; b++) start[b + 1] += start[b];
-         for (long long k = 0; k < n_sel; k++) s->h_tile_order[start[16 - cls(s->h_tile_cost[k])]++] = (int)k;
+         std::vector<int> order((size_t)n_sel);
+         for (long long k = 0; k < n_sel; k++) order[(size_t)start[16 - cls(s->h_tile_cost[k])]++] = (int)k;
+         const bool same = s->order_valid && memcmp(key, s->order_key, sizeof key) == 0 &&
+                           memcmp(order.data(), s->h_tile_order, sizeof(int) * (size_t)n_sel) == 0;
+         if (!same) {         /* an unchanged order (a still camera) is not uploaded again */
+            memcpy(s->h_tile_order, order.data(), sizeof(int) * (size_t)n_sel);
+            s->order_dirty = true;
+         }
          memcpy(s->order_key, key, sizeof key);
          s->order_valid = true;
       }
