@@ -24,6 +24,31 @@ __global__ __launch_bounds__(256) void k(const uint4 *tab, unsigned n, int iters
       if (MODE == 0) {
          const uint4 *p = tab + (size_t)idx * 4;
          v0 = p[0]; if (CHUNKS > 1) v1 = p[1]; if (CHUNKS > 2) v2 = p[2]; if (CHUNKS > 3) v3 = p[3];
+      } else if (MODE == 3) {
+         /* D: 56 of the 64 bytes: three 16-byte loads and one 8-byte load (hand-placed: the compiler widens the last) */
+         const uint4 *p = tab + (size_t)idx * 4;
+         uint2 w;
+         asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                      "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx2 %3, %4, off offset:48\n\ts_waitcnt vmcnt(0)"
+                      : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(w) : "v"(p) : "memory");
+         v3.x = w.x; v3.y = w.y; v3.z = 0; v3.w = w.y;
+      } else if (MODE == 4) {
+         /* E: the same 64 bytes as eight 8-byte loads (twice the requests) */
+         const uint4 *p = tab + (size_t)idx * 4;
+         uint2 a0, a1, a2, a3, a4, a5, a6, a7;
+         asm volatile("global_load_dwordx2 %0, %8, off\n\tglobal_load_dwordx2 %1, %8, off offset:8\n\t"
+                      "global_load_dwordx2 %2, %8, off offset:16\n\tglobal_load_dwordx2 %3, %8, off offset:24\n\t"
+                      "global_load_dwordx2 %4, %8, off offset:32\n\tglobal_load_dwordx2 %5, %8, off offset:40\n\t"
+                      "global_load_dwordx2 %6, %8, off offset:48\n\tglobal_load_dwordx2 %7, %8, off offset:56\n\ts_waitcnt vmcnt(0)"
+                      : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), "=&v"(a7) : "v"(p) : "memory");
+         v0 = make_uint4(a0.x, a0.y, a1.x, a1.y); v1 = make_uint4(a2.x, a2.y, a3.x, a3.y);
+         v2 = make_uint4(a4.x, a4.y, a5.x, a5.y); v3 = make_uint4(a6.x, a6.y, a7.x, a7.y);
+      } else if (MODE == 5) {
+         /* F: all 64 bytes with hand-placed loads, the reference point for D and E */
+         const uint4 *p = tab + (size_t)idx * 4;
+         asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                      "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48\n\ts_waitcnt vmcnt(0)"
+                      : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(p) : "memory");
       } else if (MODE == 2) {
          /* C: the first LDSREC records are also held in LDS; a fetch of one of them goes there */
          if (idx < LDSREC) {
@@ -71,5 +96,6 @@ int main()
    run<0, 4>(tab, n, iters, out, 1024, 0); run<0, 4>(tab, n, iters, out, 1024, 32); run<0, 4>(tab, n, iters, out, 1024, 512); run<0, 4>(tab, n, iters, out, 1024, 1024);
    run<1, 4>(tab, n, iters, out, 1024, 128); run<1, 4>(tab, n, iters, out, 1024, 0);
    run<2, 4>(tab, n, iters, out, 1024, 128); run<2, 4>(tab, n, iters, out, 1024, 0);
+   run<5, 4>(tab, n, iters, out, 1024, 128); run<3, 4>(tab, n, iters, out, 1024, 128); run<4, 4>(tab, n, iters, out, 1024, 128);
    return 0;
 }
