@@ -55,6 +55,7 @@ struct DScene {
    const rt_dev_light *lights;
    const rt_dev_texinfo *tex_info;
    const uchar4 *texels;
+   const int *prim_ids;     /* primitive id (the caller's numbering) of device primitive k; see rt_scene_create */
    int n_prims, n_planes, n_lights, root;
    int fast_ok;      /* every BVH bound is finite and below 2^40 in magnitude */
    int any_xform;    /* some BVH primitive carries a transform */
@@ -1116,14 +1117,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_untile(const uchar4 *tiles, long l
 }
 
 /* scatter per-slot values to the row-major sample grid (parity views) */
-__global__ __launch_bounds__(RT_BLOCK) void k_unslot_hits(DGrid g, const Hit *hits, long long n, int *prim, float *t)
+__global__ __launch_bounds__(RT_BLOCK) void k_unslot_hits(DGrid g, const Hit *hits, long long n, const int *prim_ids, int n_prims,
+                                                          int *prim, float *t)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
    if (i >= n) return;
    int X, Y;
    if (!slot_to_sample(g, i, X, Y)) return;
    long long idx = (long long)Y * g.res_w + X;
-   prim[idx] = hits[i].prim; t[idx] = hits[i].t;
+   int p = hits[i].prim;
+   prim[idx] = (p >= 0 && p < n_prims) ? prim_ids[p] : p;      /* the caller's numbering; planes follow the BVH primitives */
+   t[idx] = hits[i].t;
 }
 __global__ __launch_bounds__(RT_BLOCK) void k_unslot_rgb(DGrid g, const float *rgb, long long n, float *out)
 {
@@ -1183,6 +1187,7 @@ struct rt_scene {
    hipEvent_t ev_chain[RT_RING], ev_side[RT_RING], ev_begin, ev_end;
    bool streams_ok;
    std::vector<hipEvent_t> timing_events;   /* spare events of the per-frame timers */
+   std::vector<int32_t> prim_ids_host;      /* host copy of DScene::prim_ids */
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1294,18 +1299,40 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->ms_build_host = std::chrono::duration<float, std::milli>(t1 - t0).count();
 
    const rt_flat_scene &h = s->host;
-   enum { N_ARR = 9 };
+   /* On the device the primitives are numbered by their place among the tree's leaves (formBVH's sorted order), not
+    * by the caller's order: a leaf reference is then its position, which a tree with computed child slots needs, and
+    * neighbouring leaves have neighbouring records.  prim_ids maps back wherever an id leaves the device. */
+   const size_t np_ = (size_t)(h.n_prims > 0 ? h.n_prims : 0);
+   std::vector<int32_t> pos_of(np_, -1), ids(np_);
+   bool perm_ok = h.leaf_order != nullptr;
+   for (size_t k = 0; k < np_ && perm_ok; k++) {
+      int32_t pr = h.leaf_order[k];
+      if (pr < 0 || (size_t)pr >= np_ || pos_of[(size_t)pr] >= 0) perm_ok = false; else pos_of[(size_t)pr] = (int32_t)k;
+   }
+   for (size_t k = 0; k < np_; k++) { if (!perm_ok) pos_of[k] = (int32_t)k; ids[k] = perm_ok ? h.leaf_order[k] : (int32_t)k; }
+   std::vector<rt_dev_prim> d_prims(np_); std::vector<rt_dev_xform> d_xforms(np_); std::vector<rt_dev_shade> d_shades(np_);
+   for (size_t k = 0; k < np_; k++) { d_prims[k] = h.prims[ids[k]]; d_xforms[k] = h.xforms[ids[k]]; d_shades[k] = h.shades[ids[k]]; }
+   std::vector<rt_bvh_node> d_nodes((size_t)(h.n_nodes > 0 ? h.n_nodes : 0));
+   for (size_t k = 0; k < d_nodes.size(); k++) {
+      d_nodes[k] = h.nodes[k];
+      if (d_nodes[k].left < 0) d_nodes[k].left = ~pos_of[(size_t)~d_nodes[k].left];
+      if (d_nodes[k].right < 0) d_nodes[k].right = ~pos_of[(size_t)~d_nodes[k].right];
+   }
+   s->prim_ids_host = ids;
+   enum { N_ARR = 10 };
    size_t off[N_ARR + 1], sizes[N_ARR] = {
       sizeof(rt_bvh_node) * (size_t)h.n_nodes, sizeof(rt_dev_prim) * (size_t)h.n_prims,
       sizeof(rt_dev_xform) * (size_t)h.n_prims, sizeof(rt_dev_shade) * (size_t)h.n_prims,
       sizeof(rt_dev_plane) * (size_t)h.n_planes, sizeof(rt_material) * (size_t)h.n_materials,
-      sizeof(rt_dev_light) * (size_t)h.n_lights, sizeof(rt_dev_texinfo) * (size_t)h.n_textures, 4 * h.n_texels};
+      sizeof(rt_dev_light) * (size_t)h.n_lights, sizeof(rt_dev_texinfo) * (size_t)h.n_textures, 4 * h.n_texels,
+      sizeof(int32_t) * np_};
    off[0] = 0;
    for (int k = 0; k < N_ARR; k++) off[k + 1] = off[k] + align_up(sizes[k] ? sizes[k] : 64, 256);
    s->dev_bytes = off[N_ARR];
    hipError_t e = hipMalloc(&s->dev_blob, s->dev_bytes);
    if (e != hipSuccess) { rt_set_error("hipMalloc(%zu) failed: %s", s->dev_bytes, hipGetErrorString(e)); rt_scene_destroy(s); return RT_ERR_HIP; }
-   const void *src[N_ARR] = {h.nodes, h.prims, h.xforms, h.shades, h.planes, h.materials, h.lights, h.tex_info, h.texels};
+   const void *src[N_ARR] = {d_nodes.data(), d_prims.data(), d_xforms.data(), d_shades.data(), h.planes, h.materials, h.lights, h.tex_info,
+                             h.texels, ids.data()};
    for (int k = 0; k < N_ARR; k++) {
       if (!sizes[k]) continue;
       e = hipMemcpy((char *)s->dev_blob + off[k], src[k], sizes[k], hipMemcpyHostToDevice);
@@ -1317,7 +1344,9 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->d.planes = (const rt_dev_plane *)(b + off[4]); s->d.materials = (const rt_material *)(b + off[5]);
    s->d.lights = (const rt_dev_light *)(b + off[6]);
    s->d.tex_info = (const rt_dev_texinfo *)(b + off[7]); s->d.texels = (const uchar4 *)(b + off[8]);
-   s->d.n_prims = h.n_prims; s->d.n_planes = h.n_planes; s->d.n_lights = h.n_lights; s->d.root = h.root;
+   s->d.prim_ids = (const int *)(b + off[9]);
+   s->d.n_prims = h.n_prims; s->d.n_planes = h.n_planes; s->d.n_lights = h.n_lights;
+   s->d.root = (h.root < 0 && h.root != RT_ROOT_EMPTY) ? ~pos_of[(size_t)~h.root] : h.root;
    s->d.fast_ok = h.bounds_in_range;
    s->d.any_xform = h.any_xform;
 
@@ -1687,7 +1716,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             ev.end(tm, S); st.launches_trace++;
          }
          if (view == VIEW_PRIMARY) {
-            hipLaunchKernelGGL(k_unslot_hits, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, g, (const Hit *)hits, np, prim_dev, t_dev);
+            hipLaunchKernelGGL(k_unslot_hits, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, g, (const Hit *)hits, np, sc.prim_ids, sc.n_prims, prim_dev, t_dev);
             HIP_TRY(hipEventRecord(s->ev_side[r], S));
             continue;
          }
@@ -1905,7 +1934,11 @@ extern "C" int rt_trace_rays(const rt_scene *cs, int64_t n, const float *rays_ho
       std::vector<Hit> h((size_t)n);
       hipError_t e = hipMemcpy(h.data(), d_h, sizeof(Hit) * (size_t)n, hipMemcpyDeviceToHost);
       if (e != hipSuccess) { rt_set_error("rt_trace_rays: %s", hipGetErrorString(e)); rc = RT_ERR_HIP; }
-      else for (int64_t i = 0; i < n; i++) { prim_host[i] = h[(size_t)i].prim; t_host[i] = h[(size_t)i].t; }
+      else for (int64_t i = 0; i < n; i++) {
+         int p = h[(size_t)i].prim;
+         prim_host[i] = (p >= 0 && (size_t)p < s->prim_ids_host.size()) ? s->prim_ids_host[(size_t)p] : p;
+         t_host[i] = h[(size_t)i].t;
+      }
    }
    if (d_q) (void)hipFree(d_q);
    if (d_h) (void)hipFree(d_h);
