@@ -1619,12 +1619,13 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    for (int attempt = 0;; attempt++) {
       memset(&st, 0, sizeof st);
       attempts = attempt + 1;
-      /* chunk size: a chunk is bounded by its queue entries (2^24 primaries), by its shadow feelers (one
-       * flag byte per light per queue entry, 2^28 of them) and wants to be a quarter of the frame or less
-       * so that the two streams have something to overlap, but not so small that launches dominate */
+      /* chunk size: a chunk is bounded by its queue entries (2^24 primaries) and by its shadow feelers (one flag
+       * byte per light per queue entry; their number must stay below 2^31 for the shadow items' numbering: up to
+       * two gigabytes of flags); a frame is one chunk whenever that allows */
       double F = max_rec > 1 ? (double)s->node_factor : 1.0;
       long long slots_cap = max_batch_slots();
-      if (L > 0 && (double)slots_cap * F * L > (double)(1LL << 28)) slots_cap = (long long)((double)(1LL << 28) / (F * L));
+      const double flag_cap = (double)((1LL << 31) - (1LL << 26));
+      if (L > 0 && ((double)slots_cap * F + 64.0) * L > flag_cap) slots_cap = (long long)((flag_cap / L - 64.0) / F);
       long long tiles_cap = slots_cap / per_tile; if (tiles_cap < 1) tiles_cap = 1;
       long long tiles_min = (128 * 1024) / per_tile; if (tiles_min < 1) tiles_min = 1;
       long long chunk_tiles = n_sel;
