@@ -365,6 +365,7 @@ struct TraceArgs {
    DCamera cam;                 /* the first n entries are the primaries of grid `g`: made here, on fetch */
    DGrid g;
    SpawnRec *recs;
+   float4 *points;              /* per queue entry that hit something: the hit point and the primitive, for its shadow feelers */
    unsigned *tail;              /* next free queue entry; starts at n */
    unsigned cap;                /* entries the queue has room for */
    int max_rec;
@@ -593,6 +594,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       }
       stat_count(stats, ST_SHADE_NODES, shaded);
       bool want_sh = shaded && sc.n_lights > 0;
+      if (want_sh) {
+         /* the shaded point (kernel.cu:340) and its primitive, once, for the feelers of all its lights */
+         F3 P = ray_point(c.r, t);
+         a.points[idx] = make_float4(P.x, P.y, P.z, __int_as_float(closest));
+      }
       unsigned long long mR = __ballot(want_refl), mT = __ballot(want_refr), mS = __ballot(want_sh);
       unsigned cR = __popcll(mR), cT = __popcll(mT), cS = __popcll(mS);
       if (cR + cT + cS) {
@@ -672,12 +678,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                /* the feeler of light k for queue entry `node` (PointLight.h:18-20): from the light to the shaded point */
                unsigned code = item & ~RT_SHADOW_ITEM;
                unsigned k = code / a.cap, node = code - k * a.cap;
-               QRay q = load_qray_written(a.rays, node);
-               unsigned long long hw = __hip_atomic_load(reinterpret_cast<unsigned long long *>(a.hits + node), __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT);
-               int hprim = (int)(unsigned)hw; float ht = __uint_as_float((unsigned)(hw >> 32));
-               Ray ray; ray.o = mk3(q.ox, q.oy, q.oz); ray.d = mk3(q.dx, q.dy, q.dz);
-               F3 P = ray_point(ray, ht);                                    /* kernel.cu:340 */
+               unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.points + node);
+               unsigned long long p01 = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+               unsigned long long p23 = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+               F3 P = mk3(__uint_as_float((unsigned)p01), __uint_as_float((unsigned)(p01 >> 32)), __uint_as_float((unsigned)p23));
+               int hprim = (int)(unsigned)(p23 >> 32);
                const rt_dev_light &Lt = sc.lights[k];
                Ray feeler; feeler.o = mk3(Lt.pos[0], Lt.pos[1], Lt.pos[2]); feeler.d = P - feeler.o;
                if ((int)k + 1 < sc.n_lights) { item += a.cap; put_back = true; }     /* same entry, next light */
@@ -1644,6 +1649,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       auto carve = [&](size_t bytes) { size_t o = used; used += align_up(bytes ? bytes : 1, 256); return o; };
       const size_t o_queue = carve(sizeof(QRay) * (size_t)cap), o_hits = carve(sizeof(Hit) * (size_t)cap);
       const size_t o_recs = carve(sizeof(SpawnRec) * (size_t)cap), o_totals = carve(sizeof(float) * 3 * (size_t)cap);
+      const size_t o_points = carve(sizeof(float4) * (size_t)cap);
       const size_t o_rgb = carve(sizeof(float) * 3 * (size_t)np_max);
       const size_t n_feelers = (size_t)(L > 0 ? L : 0) * (size_t)cap;
       const size_t o_flags = carve(n_feelers);
@@ -1702,6 +1708,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             a.rays = queue; a.n = (unsigned long long)np; a.hits = hits; a.next = ctr.next_chain;
             a.flags = AT(unsigned char, r, o_flags);
             a.recs = recs; a.tail = ctr.tail; a.cap = cap; a.max_rec = max_rec; a.cam = cam; a.g = g;
+            a.points = AT(float4, r, o_points);
             a.per_tile = (unsigned)per_tile;
             a.lists = s->d_lists; a.list_cap = s->list_cap;
             if (!a.lists || a.list_cap == 0 || (a.list_cap & (a.list_cap - 1)) != 0) { rt_set_error("internal: spawn lists not set up"); return RT_ERR_HIP; }
