@@ -245,8 +245,10 @@ int rt_render(const rt_scene *scene, const rt_render_params *params,
 
 /* Same, output left in DEVICE memory (`out_rgba_dev`, layout per
  * params->out_layout), work enqueued on `stream` (a hipStream_t, may be NULL
- * for the default stream).  Returns after the stream has been synchronised
- * (the wavefront queue sizes are read back between depth levels).
+ * for the default stream).  Returns after the frame is complete: its statistics,
+ * and the per-tile costs that order the next frame's tiles, come back with it.
+ * A scene owns its working buffers (ray queue, spawn lists, tile order), so calls
+ * on one scene must not overlap; callers that render concurrently use one scene each.
  * Bytes needed: RT_OUT_FRAME width*height*4; RT_OUT_TILES rt_tile_count()*RT_TILE*RT_TILE*4. */
 int rt_render_device(const rt_scene *scene, const rt_render_params *params,
                      void *out_rgba_dev, void *stream, rt_stats *stats);
