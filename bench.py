@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-A step is one frame: generate -> extend -> shadow -> shade (per depth level) -> combine -> resolve,
+A step is one frame: one persistent traversal launch (primaries, bounces, shadow feelers) -> light sums -> combine -> resolve,
 with the scene and BVH already resident in HBM and the 8-bit frame left in HBM.  With N > 1 (one
 process per GPU, launched by torch.distributed.run) the frame is sharded by 32x32-pixel tiles, tile k
 to rank k mod N, the scene is replicated, and the compact tile buffers are gathered to rank 0 over

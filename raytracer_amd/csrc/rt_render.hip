@@ -40,7 +40,6 @@
 #include "rt_device.h"
 
 #define RT_BLOCK 256
-#define RT_RING 4            /* chunks of a frame that may be in flight at once (each owns a slice of the arena) */
 
 /* ======================================================================= */
 /* device-side views                                                        */
@@ -1172,7 +1171,7 @@ struct rt_scene {
    size_t dev_bytes;
    float ms_build_host, ms_upload, ms_build_device;
    Arena arena;             /* per-frame queues; grown on demand, reused across frames */
-   unsigned long long *d_ctr;    /* work counters of the chunks in flight: RT_RING x 8 words (see ChunkCtr) */
+   unsigned long long *d_ctr;    /* work counters of the chunk in flight: 8 words (see ChunkCtr) */
    unsigned long long *d_stats;
    unsigned long long *h_stats;  /* pinned */
    float node_factor;       /* queue entries per primary ray the chain kernel gets room for; grows when a frame overflows */
@@ -1185,11 +1184,9 @@ struct rt_scene {
    long long order_cap;                   /* tiles the four arrays have room for */
    long long order_key[6];                /* width, height, samples, tile_first, tile_stride, tiles of the frame the order is for */
    bool order_valid, order_dirty;         /* dirty: h_tile_order differs from what d_tile_order holds */
-   /* Two internal streams: `chain` traces the bounce trees of one chunk of tiles after the other, `side` runs
-    * the shadow rays, light sums, combine and resolve of the chunks the chain is through with, so that the
-    * tail of each traversal launch (its longest rays) overlaps the bulk of the other stream's. */
-   hipStream_t chain, side;
-   hipEvent_t ev_chain[RT_RING], ev_side[RT_RING], ev_begin, ev_end;
+   /* The frame's work runs on one internal stream, chunk after chunk; the caller's stream only brackets it. */
+   hipStream_t chain;
+   hipEvent_t ev_begin, ev_end;
    bool streams_ok;
    std::vector<hipEvent_t> timing_events;   /* spare events of the per-frame timers */
    std::vector<int32_t> prim_ids_host;      /* host copy of DScene::prim_ids */
@@ -1238,8 +1235,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
    if (s->h_tile_order) (void)hipHostFree(s->h_tile_order);
    for (hipEvent_t e : s->timing_events) (void)hipEventDestroy(e);
    if (s->streams_ok) {
-      (void)hipStreamDestroy(s->chain); (void)hipStreamDestroy(s->side);
-      for (int l = 0; l < RT_RING; l++) { (void)hipEventDestroy(s->ev_chain[l]); (void)hipEventDestroy(s->ev_side[l]); }
+      (void)hipStreamDestroy(s->chain);
       (void)hipEventDestroy(s->ev_begin); (void)hipEventDestroy(s->ev_end);
    }
    rt_flat_scene_free(&s->host);
@@ -1355,17 +1351,13 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->d.fast_ok = h.bounds_in_range;
    s->d.any_xform = h.any_xform;
 
-   if (hipMalloc((void **)&s->d_ctr, RT_RING * 8 * sizeof(unsigned long long)) != hipSuccess ||
+   if (hipMalloc((void **)&s->d_ctr, 8 * sizeof(unsigned long long)) != hipSuccess ||
        hipMalloc((void **)&s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long)) != hipSuccess ||
        hipHostMalloc((void **)&s->h_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
       rt_set_error("allocation of queue counters failed"); rt_scene_destroy(s); return RT_ERR_HIP;
    }
    {
       bool ok = hipStreamCreateWithFlags(&s->chain, hipStreamNonBlocking) == hipSuccess;
-      ok = ok && hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) == hipSuccess;
-      for (int l = 0; l < RT_RING && ok; l++)
-         ok = hipEventCreateWithFlags(&s->ev_chain[l], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&s->ev_side[l], hipEventDisableTiming) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&s->ev_begin, hipEventDisableTiming) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&s->ev_end, hipEventDisableTiming) == hipSuccess;
       if (!ok) { rt_set_error("stream / event creation failed"); rt_scene_destroy(s); return RT_ERR_HIP; }
@@ -1617,8 +1609,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    const long long per_tile = (long long)g.ts * g.ts;
    size_t lds_bytes = 0;
    { int rc = trace_lds_bytes(s, &lds_bytes); if (rc != RT_OK) return rc; }
-   hipStream_t M = s->chain, H = s->side;
-   { const char *e = getenv("RT_SINGLE_STREAM"); if (e && atoi(e)) H = M; }
+   hipStream_t M = s->chain;
 
    int attempts = 0;
    for (int attempt = 0;; attempt++) {
@@ -1638,7 +1629,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       if (chunk_tiles > tiles_cap) chunk_tiles = tiles_cap;
       if (chunk_tiles > n_sel) chunk_tiles = n_sel;
       const long long n_chunks = (n_sel + chunk_tiles - 1) / chunk_tiles;
-      const int ring = (int)(n_chunks < RT_RING ? n_chunks : RT_RING);
+      const int ring = 1;        /* the chunks of a frame run one after the other on one stream: one slice of the arena serves them all */
 
       /* one arena slice per chunk in flight, sized for the largest chunk */
       const long long np_max = chunk_tiles * per_tile;
@@ -1677,14 +1668,12 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       }
       const bool have_order = track_cost && s->order_valid && memcmp(key, s->order_key, sizeof key) == 0;
 
-      /* the caller's stream brackets the frame; the work itself runs on the two internal streams */
+      /* the caller's stream brackets the frame; the work itself runs on the scene's stream */
       EventPool ev(s->timing_events);
       Timer &t_total = ev.begin(stream, &st.ms_total);
       HIP_TRY(hipEventRecord(s->ev_begin, stream));
       HIP_TRY(hipStreamWaitEvent(M, s->ev_begin, 0));
 
-      HIP_TRY(hipEventRecord(s->ev_chain[0], M));                       /* the zeroed statistics */
-      if (H != M) HIP_TRY(hipStreamWaitEvent(H, s->ev_chain[0], 0));
       for (long long c = 0; c < n_chunks; c++) {
          const int r = (int)(c % ring);
          hipStream_t S = M;
@@ -1697,7 +1686,6 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          Hit *hits = AT(Hit, r, o_hits);
          SpawnRec *recs = AT(SpawnRec, r, o_recs);
 
-         if (c >= ring) HIP_TRY(hipStreamWaitEvent(S, s->ev_side[r], 0));     /* the slice's previous chunk is done with it */
          {
             /* counters to zero, spawned rays appended behind the primaries, tile costs and (first chunk) statistics cleared */
             const int n_stats = c == 0 ? ST_COUNT * RT_STAT_REPL : 0, n_cost = track_cost ? (int)n_sel : 0;
@@ -1725,7 +1713,6 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          }
          if (view == VIEW_PRIMARY) {
             hipLaunchKernelGGL(k_unslot_hits, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, g, (const Hit *)hits, np, sc.prim_ids, sc.n_prims, prim_dev, t_dev);
-            HIP_TRY(hipEventRecord(s->ev_side[r], S));
             continue;
          }
          {
@@ -1750,18 +1737,15 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          } else {
             hipLaunchKernelGGL(k_unslot_rgb, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, g, (const float *)AT(float, r, o_rgb), np, rgb_dev);
          }
-         HIP_TRY(hipEventRecord(s->ev_side[r], S));
          HIP_TRY(hipGetLastError());
       }
 #undef AT
-      for (int r = 0; r < ring; r++) HIP_TRY(hipStreamWaitEvent(M, s->ev_side[r], 0));
       HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipMemcpyDeviceToHost, M));
       HIP_TRY(hipEventRecord(s->ev_end, M));
       HIP_TRY(hipStreamWaitEvent(stream, s->ev_end, 0));
       ev.end(t_total, stream);
       HIP_TRY(hipStreamSynchronize(stream));
       HIP_TRY(hipStreamSynchronize(M));
-      HIP_TRY(hipStreamSynchronize(H));
       HIP_TRY(hipGetLastError());
       ev.collect();
       if (sum_stat(s->h_stats, ST_ABORTED) != 0) { rt_set_error("traversal aborted: step cap reached (corrupt scene?)"); return RT_ERR_HIP; }
