@@ -352,14 +352,12 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2 };
 struct TraceArgs {
    QRay *rays;                  /* the queue; OUT_CHAIN appends spawned rays behind the first n */
    unsigned long long n;        /* rays to fetch (OUT_CHAIN: the primaries) */
-   const unsigned *n_dev;       /* when non-null, n is read from here instead */
    Hit *hits;
    unsigned char *flags;        /* OUT_CHAIN: isInShadow of (light k, queue entry i) at flags[k*cap + i] */
    unsigned long long *next;    /* this launch's zeroed fetch counter */
    unsigned long long *stats;
    int refill_idle, node_burst; /* tuning: idle lanes that trigger a refill, node steps between two leaf steps */
    int take_oldest;             /* lanes of a refill that take the oldest list entries instead of the newest */
-   int stack_depth;             /* entries per lane of the traversal stack in LDS */
    /* OUT_CHAIN */
    DCamera cam;                 /* the first n entries are the primaries of grid `g`: made here, on fetch */
    DGrid g;
@@ -472,7 +470,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    int list_count = 0, list_head = 0;
    auto list_put = [&](int k, unsigned v) { list[(list_head + k) & list_mask] = v; };
    auto list_get = [&](int k) { return __hip_atomic_load(list + ((list_head + k) & list_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-   const unsigned long long n = a.n_dev ? (unsigned long long)*a.n_dev : a.n;
+   const unsigned long long n = a.n;
    unsigned long long *const stats = a.stats;
    const unsigned long long clock_start = COUNT ? wall_clock64() : 0ULL;     /* 100 MHz */
 #ifdef RT_DEBUG_EXIT_HIST
@@ -1534,7 +1532,6 @@ static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs 
    unsigned long long want = (n_hint + RT_BLOCK - 1) / RT_BLOCK;
    unsigned blocks = (unsigned)(want < (unsigned long long)g_trace_blocks ? want : (unsigned long long)g_trace_blocks);
    if (blocks == 0) return;
-   a.stack_depth = s->host.tree_depth > 0 ? s->host.tree_depth : 1;
    {
       static int refill = 0, burst = 0;
       if (!refill) { const char *e = getenv("RT_REFILL_IDLE"); refill = e && atoi(e) > 0 ? atoi(e) : RT_REFILL_IDLE; }
@@ -1553,23 +1550,23 @@ static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs 
 
 /* device counters of one chunk in flight (8 words of rt_scene::d_ctr) */
 struct ChunkCtr {
-   unsigned long long *next_chain, *next_shadow;
-   unsigned *tail, *shadow_count;
+   unsigned long long *next_chain;
+   unsigned *tail;
 };
 static ChunkCtr chunk_ctr(const rt_scene *s, int ring)
 {
    unsigned long long *b = s->d_ctr + 8 * ring;
    ChunkCtr c;
-   c.next_chain = b; c.next_shadow = b + 1;
-   c.tail = reinterpret_cast<unsigned *>(b + 2); c.shadow_count = reinterpret_cast<unsigned *>(b + 3);
+   c.next_chain = b;
+   c.tail = reinterpret_cast<unsigned *>(b + 2);
    return c;
 }
 
 /* The frame driver: body of launch_kernel after scene set-up (kernel.cu:735-760), over the tiles this call
- * selects.  The tiles are cut into chunks; a chunk is generate -> chain (its whole bounce forest in one
- * persistent launch) on one stream, then shadow set-up -> shadow trace -> light -> combine -> resolve on the
- * other.  Nothing is read back while the frame is in flight; the queue capacity per primary ray is a guess
- * that the device checks, and a frame that overflowed it is rendered again with a larger one. */
+ * selects.  The tiles are cut into chunks (one, whenever the frame fits); a chunk is four launches on the scene's
+ * stream: k_trace (every ray of the chunk), k_light, k_combine_tree, k_resolve.  Nothing is read back while the
+ * frame is in flight; the queue capacity per primary ray and the length of the waves' spawn lists are guesses
+ * that the device checks, and a frame that overflowed one is rendered again with a larger one. */
 static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, void *out_dev, int *prim_dev,
                        float *t_dev, float *rgb_dev, hipStream_t stream, rt_stats *stats_out)
 {
