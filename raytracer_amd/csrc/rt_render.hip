@@ -89,7 +89,7 @@ struct SpawnRec {
    int child_refl, child_refr;   /* index into the next level, -1 = no ray */
 };
 
-enum { ST_SHADOW_TRACED = 0, ST_SHADOW_SKIPPED, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES, ST_PRIMARY,
+enum { ST_SHADOW_SKIPPED = 0, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES,
        ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
        ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW,
        ST_ABORTED, ST_MAX_RAY_STEPS, ST_MAX_LIST, ST_OVERFLOW, ST_LIST_OVERFLOW, ST_NODES_PER_PRIMARY_X16,
@@ -488,8 +488,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    int closest = -1, cur = RT_CUR_IDLE, sp = 0, tag = 0;   /* cur: node index, ~primitive, or RT_CUR_IDLE while the lane has no ray */
    int mode = MODE_EXTEND;             /* OUT_CHAIN: what this lane's ray is */
    unsigned idx = 0;
-   unsigned n_traced = 0, n_skipped = 0;                    /* OUT_CHAIN: shadow feelers this lane traced / skipped */
-   unsigned n_primary = 0;                                  /* OUT_CHAIN: primaries this lane generated */
+   unsigned n_skipped = 0;                                  /* OUT_CHAIN: shadow feelers this lane did not have to trace */
    unsigned nv = 0, np = 0, nt = 0, wn = 0, wl = 0;
    unsigned nvs = 0, nps = 0, nts = 0;                       /* COUNT only: the same for shadow feelers */
    unsigned ray_steps = 0, max_ray_steps = 0;   /* COUNT only: wave steps this ray has been in flight */
@@ -692,7 +691,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                   float param = plane_intersect(sc, hprim - sc.n_prims, feeler);   /* kernel.cu:351 */
                   if (param == -1.0f) { a.flags[code] = 0; n_skipped++; }
                   else {
-                     n_traced++; toBeat = param; mode = MODE_SHADOW; cur = sc.root; active = true;
+                     toBeat = param; mode = MODE_SHADOW; cur = sc.root; active = true;
                      if (cur == RT_ROOT_EMPTY) finish(false);
                   }
                } else {
@@ -724,8 +723,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                      store_qray(a.rays, my, pr.o, pr.d, -FLT_MAX, inside ? 1 : 0);
                      q.ox = pr.o.x; q.oy = pr.o.y; q.oz = pr.o.z; q.to_beat = -FLT_MAX;
                      q.dx = pr.d.x; q.dy = pr.d.y; q.dz = pr.d.z; q.valid = inside ? 1 : 0;
-                     if (inside) n_primary++;
-                     else {
+                     if (!inside) {
                         /* a slot outside the frame: the result of a miss, no follow-up work */
                         Hit h; h.prim = -1; h.t = FLT_MAX; a.hits[my] = h;
                         *reinterpret_cast<float4 *>(a.recs + my) = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));
@@ -790,7 +788,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                 * still walks the tree for it; that walk is skipped here and counted separately. */
                if (dist == -1.0f) { a.flags[tag - 1] = 0; n_skipped++; active = false; cur = RT_CUR_IDLE; }
                else {
-                  n_traced++; toBeat = dist; mode = MODE_SHADOW; cur = sc.root;
+                  toBeat = dist; mode = MODE_SHADOW; cur = sc.root;
                   if (cur == RT_ROOT_EMPTY) finish(false);
                }
             } else {
@@ -832,10 +830,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
 #endif
    if (OUT == OUT_CHAIN) {
       if (lane == 0 && list_peak) atomicMax(&stats[ST_MAX_LIST * RT_STAT_REPL], (unsigned long long)list_peak);
-      unsigned long long m1 = __ballot(n_traced != 0), m2 = __ballot(n_skipped != 0);
-      if (m1) stat_add(stats, ST_SHADOW_TRACED, (unsigned long long)n_traced);
-      if (m2) stat_add(stats, ST_SHADOW_SKIPPED, (unsigned long long)n_skipped);
-      if (__ballot(n_primary != 0)) stat_add(stats, ST_PRIMARY, (unsigned long long)n_primary);
+      if (n_skipped) stat_add(stats, ST_SHADOW_SKIPPED, (unsigned long long)n_skipped);
    }
    if (COUNT) {
       stat_add(stats, ST_NODE_VISITS, (unsigned long long)nv);
@@ -1781,12 +1776,24 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       }
       break;
    }
-   st.rays_primary = sum_stat(s->h_stats, ST_PRIMARY);
-   st.rays_shadow = sum_stat(s->h_stats, ST_SHADOW_TRACED);
+   /* The primaries are the selected tiles' samples that lie inside the frame; every shaded point issues one feeler per
+    * light, traced unless its own-surface test missed: neither needs a device counter. */
+   {
+      unsigned long long inside = 0;
+      const int tiles_x = (p->width + RT_TILE - 1) / RT_TILE;
+      for (long long k = 0; k < n_sel; k++) {
+         long long tile = tile_first + k * tile_stride;
+         long long x0 = (tile % tiles_x) * RT_TILE, y0 = (tile / tiles_x) * RT_TILE;
+         long long w = p->width - x0 < RT_TILE ? p->width - x0 : RT_TILE, h = p->height - y0 < RT_TILE ? p->height - y0 : RT_TILE;
+         if (w > 0 && h > 0) inside += (unsigned long long)(w * h) * (unsigned long long)p->sample_count;
+      }
+      st.rays_primary = inside;
+   }
    st.shadow_skipped = sum_stat(s->h_stats, ST_SHADOW_SKIPPED);
    st.rays_reflect = sum_stat(s->h_stats, ST_REFLECT);
    st.rays_refract = sum_stat(s->h_stats, ST_REFRACT);
    st.shade_nodes = sum_stat(s->h_stats, ST_SHADE_NODES);
+   st.rays_shadow = st.shade_nodes * (unsigned long long)(L > 0 ? L : 0) - st.shadow_skipped;
    st.rays_total = st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract;
    st.samples = st.rays_primary;
    st.node_visits = sum_stat(s->h_stats, ST_NODE_VISITS); st.prim_tests = sum_stat(s->h_stats, ST_PRIM_TESTS); st.tie_events = sum_stat(s->h_stats, ST_TIES);
