@@ -97,3 +97,27 @@ def test_smooth_mesh_cook_torrance_four_strata():
     sd.camera = dict(sd.camera, pos=np.array([0.1, 0.7, 1.5], np.float32), look_at=np.array([-0.15, 0.35, 0.0], np.float32))
     st = compare(sd, 128, 96, samples=4, shading=abi.RT_COOK_TORRANCE, rgb_tol=1e-3)
     assert st["shade_nodes"] > 0.2 * st["rays_primary"]
+
+
+def test_scheduling_knobs_do_not_change_a_pixel():
+    """Tile start order, list draining order, refill threshold and burst length only schedule the work: frames rendered
+    in child processes with each of them changed are the bytes of the frame rendered here."""
+    import hashlib
+    import subprocess
+    import sys
+    sd_path = os.path.join(GOLDEN, "scenes", "recurse_simp2.npz")
+    with ra.Scene(ra.SceneData.load(sd_path)) as sc:
+        sc.render(256, 192, 4)
+        want, _ = sc.render(256, 192, 4)                 # the second frame uses the first one's tile costs
+    digest = hashlib.sha256(want.tobytes()).hexdigest()
+    code = ("import hashlib, sys, raytracer_amd as ra\n"
+            "sc = ra.Scene(ra.SceneData.load(sys.argv[1]))\n"
+            "sc.render(256, 192, 4); f, _ = sc.render(256, 192, 4)\n"
+            "print(hashlib.sha256(f.tobytes()).hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for knobs in ({"RT_TILE_ORDER": "0"}, {"RT_TAKE_OLDEST": "0"}, {"RT_REFILL_IDLE": "40", "RT_NODE_BURST": "3"},
+                  {"RT_CHUNK_TILES": "7"}):
+        env = dict(os.environ, PYTHONPATH=root, **knobs)
+        out = subprocess.run([sys.executable, "-c", code, sd_path], env=env, capture_output=True, text=True, timeout=100)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip().splitlines()[-1] == digest, knobs
