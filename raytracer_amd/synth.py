@@ -104,3 +104,68 @@ def from_obj(path, pigment=(0.85, 0.8, 0.7)):
     sd.camera = {"pos": np.array([1, 6, 12], np.float32), "up": np.array([0, 1, 0], np.float32),
                  "right": np.array([1.33, 0, 0], np.float32), "look_at": np.array([0, 0, 0], np.float32)}
     return sd
+
+
+def random_scene(seed, n_spheres=12, n_triangles=10, n_boxes=5, n_smooth=6, n_planes=1, n_lights=2):
+    """A small scene of every primitive class with random placement, random scale / rotate / translate modifiers on
+    half of the objects (stored, like the reference's mat4, column-major, with the matching inverse) and random
+    finishes, a third of them reflecting, a fifth refracting.  For parity runs over many seeds."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+
+    def modifiers(n):
+        mod = identity_modifier(n)
+        m = mod["mat"]
+        m["clr"] = rng.random((n, 3)).astype(np.float32)
+        m["amb"], m["dif"] = 0.1 + 0.2 * rng.random(n), 0.3 + 0.5 * rng.random(n)
+        m["spec"], m["rough"] = 0.6 * rng.random(n), 0.02 + 0.3 * rng.random(n)
+        refl, refr = rng.random(n) < 1 / 3, rng.random(n) < 1 / 5
+        m["refl"] = np.where(refl, 0.2 + 0.6 * rng.random(n), 0.0)
+        m["refr"] = np.where(refr, 1.0, 0.0)
+        m["alpha"] = np.where(refr, 0.3 + 0.6 * rng.random(n), 0.0)
+        m["ior"] = np.where(refr, 1.1 + 0.6 * rng.random(n), 1.0)
+        for k in range(n):
+            if rng.random() < 0.5:
+                continue
+            sc = np.diag(np.append(0.5 + rng.random(3), 1.0))
+            a, b = rng.random(2) * 2 * np.pi
+            ry = np.array([[np.cos(a), 0, np.sin(a), 0], [0, 1, 0, 0], [-np.sin(a), 0, np.cos(a), 0], [0, 0, 0, 1]])
+            rx = np.array([[1, 0, 0, 0], [0, np.cos(b), -np.sin(b), 0], [0, np.sin(b), np.cos(b), 0], [0, 0, 0, 1]])
+            tr = np.eye(4); tr[:3, 3] = rng.random(3) - 0.5
+            mat = (tr @ ry @ rx @ sc).astype(np.float32)
+            mod["trans"][k] = mat.T.reshape(16)
+            mod["inv_trans"][k] = np.linalg.inv(mat.astype(np.float64)).astype(np.float32).T.reshape(16)
+        return mod
+
+    def points(n, spread=4.0):
+        return ((rng.random((n, 3)) - 0.5) * spread).astype(np.float32)
+
+    sd = SceneData()
+    sp = np.zeros(n_spheres, abi.sphere_dtype)
+    sp["c"], sp["r"], sp["mod"] = points(n_spheres), (0.2 + 0.6 * rng.random(n_spheres)).astype(np.float32), modifiers(n_spheres)
+    sd.spheres = sp
+    tr = np.zeros(n_triangles, abi.triangle_dtype)
+    base = points(n_triangles)
+    tr["p1"], tr["p2"], tr["p3"] = base, base + points(n_triangles, 1.5), base + points(n_triangles, 1.5)
+    tr["mod"] = modifiers(n_triangles)
+    sd.triangles = tr
+    bx = np.zeros(n_boxes, abi.box_dtype)
+    lo = points(n_boxes)
+    bx["p1"], bx["p2"], bx["mod"] = lo, lo + (0.2 + rng.random((n_boxes, 3))).astype(np.float32), modifiers(n_boxes)
+    sd.boxes = bx
+    st = np.zeros(n_smooth, abi.smooth_triangle_dtype)
+    base = points(n_smooth)
+    st["p1"], st["p2"], st["p3"] = base, base + points(n_smooth, 1.5), base + points(n_smooth, 1.5)
+    for nn in ("n1", "n2", "n3"):
+        v = rng.normal(size=(n_smooth, 3)); st[nn] = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    st["mod"] = modifiers(n_smooth)
+    sd.smooth_triangles = st
+    pl = np.zeros(n_planes, abi.plane_dtype)
+    pl["n"], pl["d"], pl["mod"] = (0.0, 1.0, 0.0), -2.5, modifiers(n_planes)
+    sd.planes = pl
+    lt = np.zeros(n_lights, abi.light_dtype)
+    lt["pos"] = (points(n_lights, 6.0) + np.array([0, 6, 4], np.float32))
+    lt["clr"] = (0.5 + 0.5 * rng.random((n_lights, 3))).astype(np.float32)
+    sd.lights = lt
+    sd.camera = {"pos": np.array([0, 1, 7], np.float32), "up": np.array([0, 1, 0], np.float32),
+                 "right": np.array([1.3333, 0, 0], np.float32), "look_at": np.array([0, 0, 0], np.float32)}
+    return sd

@@ -121,3 +121,16 @@ def test_scheduling_knobs_do_not_change_a_pixel():
         out = subprocess.run([sys.executable, "-c", code, sd_path], env=env, capture_output=True, text=True, timeout=100)
         assert out.returncode == 0, out.stderr
         assert out.stdout.strip().splitlines()[-1] == digest, knobs
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes(seed):
+    """Every primitive class, random modifiers and finishes (reflecting, refracting), both shaders by turns."""
+    shading = abi.RT_PHONG if seed % 2 == 0 else abi.RT_COOK_TORRANCE
+    compare(synth.random_scene(seed), 96, 72, samples=1 if seed % 3 else 4, shading=shading, seed=seed, rgb_tol=1e-3)
+
+
+@pytest.mark.parametrize("seed", (100, 101, 102))
+def test_random_scenes_with_deeper_trees(seed):
+    sd = synth.random_scene(seed, n_spheres=300, n_triangles=200, n_boxes=60, n_smooth=100, n_planes=2, n_lights=3)
+    compare(sd, 128, 96, shading=abi.RT_PHONG, seed=seed, rgb_tol=1e-3)
