@@ -134,3 +134,12 @@ def test_random_scenes(seed):
 def test_random_scenes_with_deeper_trees(seed):
     sd = synth.random_scene(seed, n_spheres=300, n_triangles=200, n_boxes=60, n_smooth=100, n_planes=2, n_lights=3)
     compare(sd, 128, 96, shading=abi.RT_PHONG, seed=seed, rgb_tol=1e-3)
+
+
+@pytest.mark.parametrize("seed", (7, 8))
+def test_random_scenes_axis_aligned_view(seed):
+    """Camera on the z axis, odd frame, no jitter: the centre column and row hold rays with a zero direction component,
+    the case the box test treats as parallel to a slab (GeometryUtil.h:9-51)."""
+    sd = synth.random_scene(seed, n_spheres=40, n_triangles=30, n_boxes=20, n_smooth=10)
+    sd.camera = dict(sd.camera, pos=np.array([0, 0, 7], np.float32), look_at=np.array([0, 0, 0], np.float32))
+    compare(sd, 65, 49, jitter=abi.RT_JITTER_NONE, rgb_tol=1e-3)
