@@ -92,7 +92,7 @@ struct SpawnRec {
 enum { ST_SHADOW_SKIPPED = 0, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES,
        ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
        ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW,
-       ST_ABORTED, ST_MAX_RAY_STEPS, ST_MAX_LIST, ST_OVERFLOW, ST_LIST_OVERFLOW, ST_NODES_PER_PRIMARY_X16,
+       ST_ABORTED, ST_MAX_RAY_STEPS, ST_MAX_LIST, ST_OVERFLOW, ST_LIST_OVERFLOW,
        ST_CLOCK_FIRST_START, ST_CLOCK_LAST_EXIT, ST_CLOCK_EXIT_SUM, ST_WAVES,
 #ifdef RT_DEBUG_EXIT_HIST
        ST_HIST, ST_COUNT = ST_HIST + 48 };    /* when each wave of the traversal launch was done, in 0.25 ms bins */
@@ -348,22 +348,26 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2 };
 #define RT_LIST_CAP_FIRST 1024u   /* entries of a wave's list to begin with; doubled when a frame overflows it */
 #define RT_LIST_CAP_MAX 65536u
 #define RT_NODE_BURST 16    /* node steps between two leaf steps / refill checks */
+#define RT_FETCH_STREAMS 64u /* counters the primaries are handed out through */
+#define RT_CTR_WORDS (8 * ((int)RT_FETCH_STREAMS + 1))   /* 64-bit words of a launch's counters: the streams' (64 bytes apart), then the queue tail */
+#define RT_RESERVE 256      /* queue entries a wave reserves at a time for the bounce rays it spawns */
 
 struct TraceArgs {
    QRay *rays;                  /* the queue; OUT_CHAIN appends spawned rays behind the first n */
    unsigned long long n;        /* rays to fetch (OUT_CHAIN: the primaries) */
    Hit *hits;
    unsigned char *flags;        /* OUT_CHAIN: isInShadow of (light k, queue entry i) at flags[k*cap + i] */
-   unsigned long long *next;    /* this launch's zeroed fetch counter */
+   unsigned long long *next;    /* this launch's zeroed fetch counters: RT_FETCH_STREAMS of them, 64 bytes apart */
    unsigned long long *stats;
    int refill_idle, node_burst; /* tuning: idle lanes that trigger a refill, node steps between two leaf steps */
    int take_oldest;             /* lanes of a refill that take the oldest list entries instead of the newest */
+   unsigned reserve;            /* OUT_CHAIN: queue entries a wave reserves per atomic for the bounce rays it spawns */
    /* OUT_CHAIN */
    DCamera cam;                 /* the first n entries are the primaries of grid `g`: made here, on fetch */
    DGrid g;
    SpawnRec *recs;
    float4 *points;              /* per queue entry that hit something: the hit point and the primitive, for its shadow feelers */
-   unsigned *tail;              /* next free queue entry; starts at n */
+   unsigned *tail;              /* next queue entry no wave has reserved; starts at n */
    unsigned cap;                /* entries the queue has room for */
    int max_rec;
    unsigned *lists;             /* one ring of list_cap (a power of two) entries per wave of the launch */
@@ -488,7 +492,17 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    int closest = -1, cur = RT_CUR_IDLE, sp = 0, tag = 0;   /* cur: node index, ~primitive, or RT_CUR_IDLE while the lane has no ray */
    int mode = MODE_EXTEND;             /* OUT_CHAIN: what this lane's ray is */
    unsigned idx = 0;
-   unsigned n_skipped = 0;                                  /* OUT_CHAIN: shadow feelers this lane did not have to trace */
+   /* Every atomic on a word that all waves of the launch share costs the chip about 12 ns (they are served one
+    * after the other, wherever the waves run): 100 000 of them are a millisecond.  So the primaries are handed out
+    * through RT_FETCH_STREAMS counters instead of one, queue entries for bounce rays are reserved a range at a time
+    * ([res_lo, res_hi)), and a wave sums its statistics in registers and adds them once, when it is done. */
+   const unsigned long long n_patches = (a.n + 63ULL) >> 6;
+   unsigned stream = (blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) % RT_FETCH_STREAMS;   /* wave-uniform: the stream this wave fetches from */
+   unsigned streams_dry = 0;                   /* wave-uniform: streams this wave has found dry */
+   unsigned res_lo = 0, res_hi = 0;            /* wave-uniform: OUT_CHAIN, queue entries reserved, not yet used */
+   bool res_full = false;                      /* wave-uniform: the queue had no entries left to reserve */
+   unsigned n_skipped = 0;                     /* OUT_CHAIN: shadow feelers this lane did not have to trace */
+   unsigned w_shaded = 0, w_refl = 0, w_refr = 0;   /* wave-uniform: OUT_CHAIN, shade nodes and bounce rays of this wave */
    unsigned nv = 0, np = 0, nt = 0, wn = 0, wl = 0;
    unsigned nvs = 0, nps = 0, nts = 0;                       /* COUNT only: the same for shadow feelers */
    unsigned ray_steps = 0, max_ray_steps = 0;   /* COUNT only: wave steps this ray has been in flight */
@@ -588,46 +602,53 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             want_refl = b.want_refl != 0; want_refr = b.want_refr != 0;
          }
       }
-      stat_count(stats, ST_SHADE_NODES, shaded);
+      w_shaded += (unsigned)__popcll(__ballot(shaded));
       bool want_sh = shaded && sc.n_lights > 0;
-      if (want_sh) {
-         /* the shaded point (kernel.cu:340) and its primitive, once, for the feelers of all its lights */
-         F3 P = ray_point(c.r, t);
-         a.points[idx] = make_float4(P.x, P.y, P.z, __int_as_float(closest));
-      }
       unsigned long long mR = __ballot(want_refl), mT = __ballot(want_refr), mS = __ballot(want_sh);
       unsigned cR = __popcll(mR), cT = __popcll(mT), cS = __popcll(mS);
       if (cR + cT + cS) {
-         unsigned leader = (unsigned)__ffsll((long long)(mR | mT | mS)) - 1;
-         unsigned base = 0;
-         if (cR + cT) {
-            if (lane == leader) base = atomicAdd(a.tail, cR + cT);
-            base = __shfl(base, leader);
-         }
-         unsigned slotR = base + __popcll(mR & below), slotT = base + cR + __popcll(mT & below);
-         bool okR = want_refl && slotR < a.cap, okT = want_refr && slotT < a.cap;
-         unsigned long long oR = __ballot(okR), oT = __ballot(okT);
-         unsigned nR = __popcll(oR), nT = __popcll(oT);
-         bool room = list != nullptr && list_count + (int)(nR + nT + cS) <= (int)a.list_cap;
-         /* in list order: the refraction ray, the reflection ray, the shadow item */
-         if (okT) {
-            store_qray(a.rays, slotT, mk3(b.to[0], b.to[1], b.to[2]), mk3(b.td[0], b.td[1], b.td[2]), -FLT_MAX, tag + 1);
-            out.child_refr = (int)slotT;
-            if (room) list_put(list_count + __popcll(oT & below), slotT);
-         }
-         if (okR) {
-            store_qray(a.rays, slotR, mk3(b.ro[0], b.ro[1], b.ro[2]), mk3(b.rd[0], b.rd[1], b.rd[2]), -FLT_MAX, tag + 1);
-            out.child_refl = (int)slotR;
-            if (room) list_put(list_count + nT + __popcll(oR & below), slotR);
-         }
-         if (want_sh && room) list_put(list_count + nT + nR + __popcll(mS & below), RT_SHADOW_ITEM | idx);   /* light 0 of entry idx */
-         if (room) list_count += (int)(nR + nT + cS);
-         list_peak = list_count > list_peak ? list_count : list_peak;
-         if (lane == leader) {
-            if (nR) stat_add(stats, ST_REFLECT, (unsigned long long)nR);
-            if (nT) stat_add(stats, ST_REFRACT, (unsigned long long)nT);
-            if (nR + nT != cR + cT) stat_add(stats, ST_OVERFLOW, 1ULL);      /* the queue is full: the host retries with a larger one */
-            if (!room) stat_add(stats, ST_LIST_OVERFLOW, 1ULL);              /* the list is full: the host retries with longer ones */
+         const bool room = list != nullptr && list_count + (int)(cR + cT + cS) <= (int)a.list_cap;
+         if (!room) {
+            /* The list is full: nothing of this stage is started (no queue entry is taken, the nodes keep "no child"),
+             * the frame is flagged and the host renders it again with longer lists. */
+            if (lane == 0) stat_add(stats, ST_LIST_OVERFLOW, 1ULL);
+         } else {
+            if (want_sh) {
+               /* the shaded point (kernel.cu:340) and its primitive, once, for the feelers of all its lights */
+               F3 P = ray_point(c.r, t);
+               a.points[idx] = make_float4(P.x, P.y, P.z, __int_as_float(closest));
+            }
+            const unsigned cnt = cR + cT;
+            if (cnt > res_hi - res_lo && !res_full) {
+               /* a new range of queue entries; what is left of the old one is never used and reads as a miss */
+               for (unsigned u = res_lo + lane; u < res_hi; u += 64) { Hit h; h.prim = -1; h.t = FLT_MAX; a.hits[u] = h; }
+               unsigned base = 0;
+               if (lane == 0) base = atomicAdd(a.tail, a.reserve);
+               base = __shfl(base, 0);
+               if (base >= a.cap) { res_lo = res_hi = 0; res_full = true; }
+               else { res_lo = base; res_hi = a.cap - base < a.reserve ? a.cap : base + a.reserve; }
+            }
+            unsigned slotR = res_lo + __popcll(mR & below), slotT = res_lo + cR + __popcll(mT & below);
+            bool okR = want_refl && slotR < res_hi, okT = want_refr && slotT < res_hi;
+            unsigned long long oR = __ballot(okR), oT = __ballot(okT);
+            unsigned nR = __popcll(oR), nT = __popcll(oT);
+            res_lo += cnt < res_hi - res_lo ? cnt : res_hi - res_lo;
+            /* in list order: the refraction rays, the reflection rays, the shadow items */
+            if (okT) {
+               store_qray(a.rays, slotT, mk3(b.to[0], b.to[1], b.to[2]), mk3(b.td[0], b.td[1], b.td[2]), -FLT_MAX, tag + 1);
+               out.child_refr = (int)slotT;
+               list_put(list_count + __popcll(oT & below), slotT);
+            }
+            if (okR) {
+               store_qray(a.rays, slotR, mk3(b.ro[0], b.ro[1], b.ro[2]), mk3(b.rd[0], b.rd[1], b.rd[2]), -FLT_MAX, tag + 1);
+               out.child_refl = (int)slotR;
+               list_put(list_count + nT + __popcll(oR & below), slotR);
+            }
+            if (want_sh) list_put(list_count + nT + nR + __popcll(mS & below), RT_SHADOW_ITEM | idx);   /* light 0 of entry idx */
+            list_count += (int)(nR + nT + cS);
+            list_peak = list_count > list_peak ? list_count : list_peak;
+            w_refl += cR; w_refr += cT;
+            if (nR + nT != cnt && lane == 0) stat_add(stats, ST_OVERFLOW, 1ULL);   /* the queue is full: the host retries with a larger one */
          }
       }
       if (pend) *reinterpret_cast<float4 *>(a.recs + idx) = make_float4(out.refl, out.alpha, __int_as_float(out.child_refl), __int_as_float(out.child_refr));
@@ -652,12 +673,21 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          int take = 0;
          if (OUT == OUT_CHAIN) take = n_idle < list_count ? n_idle : list_count;
          int need = exhausted ? 0 : n_idle - take;
-         unsigned long long base = 0;
+         /* Primaries for the idle lanes that get no list entry.  The sample slots are dealt out in patches of 64 to
+          * RT_FETCH_STREAMS streams (patch p belongs to stream p mod RT_FETCH_STREAMS), each with a counter of its own:
+          * the waves of a launch spread over the streams, so that no counter is asked more often than it can answer,
+          * and a wave whose stream has run dry moves on to the next one until it has seen them all dry.  The streams
+          * advance together, so the slots are still started in (nearly) their order. */
+         unsigned long long q_base = 0, q_len = 0;
+         const unsigned my_stream = stream;
          if (need > 0) {
-            int leader = __ffsll((long long)m_idle) - 1;
-            if ((int)lane == leader) base = atomicAdd(a.next, (unsigned long long)need);
-            base = __shfl(base, leader);
-            if (base + (unsigned long long)need >= n) exhausted = true;
+            if (lane == 0) q_base = atomicAdd(a.next + (size_t)stream * 8, (unsigned long long)need);
+            q_base = __shfl(q_base, 0);
+            q_len = n_patches > stream ? ((n_patches - stream + RT_FETCH_STREAMS - 1) / RT_FETCH_STREAMS) * 64ULL : 0ULL;
+            if (q_base + (unsigned long long)need >= q_len) {
+               stream = stream + 1 == RT_FETCH_STREAMS ? 0u : stream + 1;
+               if (++streams_dry == RT_FETCH_STREAMS) exhausted = true;
+            }
          }
          unsigned item = 0;
          bool own = !active && rank < take;
@@ -702,7 +732,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                unsigned long long my = 0;
                if (own) { my = item; have = true; }
                else if (need > 0) {
-                  my = base + (unsigned long long)(rank - take); have = my < n;
+                  const unsigned long long q = q_base + (unsigned long long)(rank - take);
+                  my = ((q >> 6) * RT_FETCH_STREAMS + my_stream) * 64ULL + (q & 63ULL);
+                  have = q < q_len && my < n;
                   if (have && OUT == OUT_CHAIN && a.tile_order) {
                      /* the k-th tile to be started is tile_order[k] of this launch's tiles; where a sample's results
                       * are stored does not change */
@@ -829,8 +861,16 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    }
 #endif
    if (OUT == OUT_CHAIN) {
-      if (lane == 0 && list_peak) atomicMax(&stats[ST_MAX_LIST * RT_STAT_REPL], (unsigned long long)list_peak);
-      if (n_skipped) stat_add(stats, ST_SHADOW_SKIPPED, (unsigned long long)n_skipped);
+      /* what is left of the reserved queue entries reads as a miss (the light sums run over every entry below the tail) */
+      for (unsigned u = res_lo + lane; u < res_hi; u += 64) { Hit h; h.prim = -1; h.t = FLT_MAX; a.hits[u] = h; }
+      for (int o = 32; o > 0; o >>= 1) n_skipped += __shfl_xor(n_skipped, o);
+      if (lane == 0) {
+         if (list_peak) atomicMax(&stats[ST_MAX_LIST * RT_STAT_REPL], (unsigned long long)list_peak);
+         if (n_skipped) stat_add(stats, ST_SHADOW_SKIPPED, (unsigned long long)n_skipped);
+         if (w_shaded) stat_add(stats, ST_SHADE_NODES, (unsigned long long)w_shaded);
+         if (w_refl) stat_add(stats, ST_REFLECT, (unsigned long long)w_refl);
+         if (w_refr) stat_add(stats, ST_REFRACT, (unsigned long long)w_refr);
+      }
    }
    if (COUNT) {
       stat_add(stats, ST_NODE_VISITS, (unsigned long long)nv);
@@ -976,24 +1016,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_begin_chunk(unsigned long long *st
    int i = (int)(blockIdx.x * RT_BLOCK + threadIdx.x);
    if (stats && i < n_stats) stats[i] = 0ULL;
    if (tile_cost && i < n_cost) tile_cost[i] = 0u;
-   if (i < 8) ctr[i] = 0ULL;
-   __syncthreads();
-   if (i == 0) *tail = n_primary;       /* tail is one of ctr's words: set after the zeroing, by the same block */
+   if (i < 8 * (int)RT_FETCH_STREAMS) ctr[i] = 0ULL;       /* the fetch counters; the tail's words follow them */
+   if (i == 0) *tail = n_primary;
 }
 
-/* light: totalLight of every node, the loop of kernel.cu:347-358 with the shadow flags.  Thread 0 also notes
- * how many queue entries the chain kernel wanted per primary (in sixteenths) so the host can size the next frame. */
+/* light: totalLight of every node, the loop of kernel.cu:347-358 with the shadow flags, over every queue entry
+ * some wave reserved (entries reserved and not used read as a miss) */
 __global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue, const Hit *hits, const unsigned char *flags,
-                                                    const unsigned *n_dev, unsigned cap, unsigned n_primary, int shading,
-                                                    float *totals, unsigned long long *stats)
+                                                    const unsigned *n_dev, unsigned cap, int shading, float *totals)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-   unsigned wanted = *n_dev;
-   unsigned n = wanted < cap ? wanted : cap;
-   if (i == 0 && n_primary > 0) {
-      unsigned long long ratio = ((unsigned long long)wanted * 16ULL + n_primary - 1) / n_primary;
-      atomicMax(&stats[ST_NODES_PER_PRIMARY_X16 * RT_STAT_REPL], ratio);
-   }
+   unsigned reserved = *n_dev;
+   unsigned n = reserved < cap ? reserved : cap;
    if (i >= (long long)n) return;
    Hit h = hits[i];
    F3 total = mk3(0.0f, 0.0f, 0.0f);
@@ -1164,7 +1198,7 @@ struct rt_scene {
    size_t dev_bytes;
    float ms_build_host, ms_upload, ms_build_device;
    Arena arena;             /* per-frame queues; grown on demand, reused across frames */
-   unsigned long long *d_ctr;    /* work counters of the chunk in flight: 8 words (see ChunkCtr) */
+   unsigned long long *d_ctr;    /* work counters of the chunk in flight: RT_CTR_WORDS words (see ChunkCtr) */
    unsigned long long *d_stats;
    unsigned long long *h_stats;  /* pinned */
    float node_factor;       /* queue entries per primary ray the chain kernel gets room for; grows when a frame overflows */
@@ -1183,6 +1217,10 @@ struct rt_scene {
    bool streams_ok;
    std::vector<hipEvent_t> timing_events;   /* spare events of the per-frame timers */
    std::vector<int32_t> prim_ids_host;      /* host copy of DScene::prim_ids */
+   /* launch shape and tuning of the traversal kernel, read once per scene from its device and the environment */
+   int trace_blocks;        /* workgroups of a full traversal launch: what the device holds at 4 waves per SIMD */
+   int refill_idle, node_burst, take_oldest, use_tile_order;
+   unsigned reserve;        /* queue entries a wave reserves at a time for its bounce rays */
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1235,6 +1273,8 @@ extern "C" void rt_scene_destroy(rt_scene *s)
    delete s;
 }
 
+static void scene_tuning(rt_scene *s);
+
 extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
 {
    if (!desc || !out) { rt_set_error("rt_scene_create_host: null argument"); return RT_ERR_BAD_ARGUMENT; }
@@ -1273,6 +1313,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false; s->order_dirty = true;
    s->d_lists = nullptr; s->list_cap = first_list_cap(); s->list_waves = 0;
    s->camera = desc->camera; s->has_camera = desc->has_camera;
+   scene_tuning(s);
 
    auto t0 = std::chrono::steady_clock::now();
    int st = rt_flatten_scene_ex(desc, flags, &s->host);
@@ -1344,7 +1385,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->d.fast_ok = h.bounds_in_range;
    s->d.any_xform = h.any_xform;
 
-   if (hipMalloc((void **)&s->d_ctr, 8 * sizeof(unsigned long long)) != hipSuccess ||
+   if (hipMalloc((void **)&s->d_ctr, RT_CTR_WORDS * sizeof(unsigned long long)) != hipSuccess ||
        hipMalloc((void **)&s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long)) != hipSuccess ||
        hipHostMalloc((void **)&s->h_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
       rt_set_error("allocation of queue counters failed"); rt_scene_destroy(s); return RT_ERR_HIP;
@@ -1475,8 +1516,6 @@ static long long max_batch_slots()
    return v > 0 ? v : (long long)(1 << 24);
 }
 
-static int g_trace_blocks = 0;
-
 static int trace_lds_bytes(const rt_scene *s, size_t *out)
 {
    /* the stack holds at most one deferred sibling per internal level */
@@ -1494,24 +1533,34 @@ static int trace_lds_bytes(const rt_scene *s, size_t *out)
 }
 
 
-/* persistent traversal launch: enough blocks to fill the chip a few times over; every wave pulls rays until
- * the queue is dry.  `n_hint` bounds the number of rays (it sizes the grid when the count lives on the device). */
-static int trace_blocks_max(const rt_scene *s)
+static int env_int(const char *name, int fallback, bool allow_zero = false)
 {
-   if (g_trace_blocks == 0) {
-      const char *e = getenv("RT_TRACE_BLOCKS");
-      int cus = 256;
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-      g_trace_blocks = e && atoi(e) > 0 ? atoi(e) : cus * 4;
-   }
-   return g_trace_blocks;
+   const char *e = getenv(name);
+   if (!e) return fallback;
+   int v = atoi(e);
+   return (v > 0 || (allow_zero && v == 0)) ? v : fallback;
+}
+
+/* The persistent traversal launch fills the device once: 4 workgroups of 256 per CU are what 128 registers per
+ * lane allow, and every wave pulls rays until the queue is dry. */
+static void scene_tuning(rt_scene *s)
+{
+   int cus = 256;
+   hipDeviceProp_t prop;
+   if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+   s->trace_blocks = env_int("RT_TRACE_BLOCKS", cus * 4);
+   s->refill_idle = env_int("RT_REFILL_IDLE", RT_REFILL_IDLE);
+   s->node_burst = env_int("RT_NODE_BURST", RT_NODE_BURST);
+   s->take_oldest = env_int("RT_TAKE_OLDEST", RT_TAKE_OLDEST, true);
+   s->use_tile_order = env_int("RT_TILE_ORDER", 1, true);
+   int r = env_int("RT_RESERVE", RT_RESERVE);
+   s->reserve = (unsigned)(r < 128 ? 128 : r);      /* one spawn stage can ask for 128 entries */
 }
 
 /* room for the lists of every wave a launch can have */
 static int ensure_lists(rt_scene *s)
 {
-   const unsigned waves = (unsigned)trace_blocks_max(s) * (RT_BLOCK / 64);
+   const unsigned waves = (unsigned)s->trace_blocks * (RT_BLOCK / 64);
    if (s->d_lists && s->list_waves == waves) return RT_OK;
    if (s->d_lists) { (void)hipFree(s->d_lists); s->d_lists = nullptr; }
    hipError_t e = hipMalloc((void **)&s->d_lists, sizeof(unsigned) * (size_t)waves * s->list_cap);
@@ -1523,19 +1572,11 @@ static int ensure_lists(rt_scene *s)
 static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs a, unsigned long long n_hint, size_t lds_bytes,
                          hipStream_t stream)
 {
-   (void)trace_blocks_max(s);
    unsigned long long want = (n_hint + RT_BLOCK - 1) / RT_BLOCK;
-   unsigned blocks = (unsigned)(want < (unsigned long long)g_trace_blocks ? want : (unsigned long long)g_trace_blocks);
+   unsigned blocks = (unsigned)(want < (unsigned long long)s->trace_blocks ? want : (unsigned long long)s->trace_blocks);
    if (blocks == 0) return;
-   {
-      static int refill = 0, burst = 0;
-      if (!refill) { const char *e = getenv("RT_REFILL_IDLE"); refill = e && atoi(e) > 0 ? atoi(e) : RT_REFILL_IDLE; }
-      if (!burst) { const char *e = getenv("RT_NODE_BURST"); burst = e && atoi(e) > 0 ? atoi(e) : RT_NODE_BURST; }
-      a.refill_idle = refill; a.node_burst = burst;
-      static int oldest = -1;
-      if (oldest < 0) { const char *e = getenv("RT_TAKE_OLDEST"); oldest = e ? atoi(e) : RT_TAKE_OLDEST; }
-      a.take_oldest = oldest;
-   }
+   a.refill_idle = s->refill_idle; a.node_burst = s->node_burst; a.take_oldest = s->take_oldest;
+   a.reserve = s->reserve;
    a.stats = s->d_stats;
 #define RT_LAUNCH_TRACE(O, C) hipLaunchKernelGGL((k_trace<O, C>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, a)
    if (out_mode == OUT_CHAIN) { if (count) RT_LAUNCH_TRACE(OUT_CHAIN, true); else RT_LAUNCH_TRACE(OUT_CHAIN, false); }
@@ -1543,17 +1584,17 @@ static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs 
 #undef RT_LAUNCH_TRACE
 }
 
-/* device counters of one chunk in flight (8 words of rt_scene::d_ctr) */
+/* device counters of the chunk in flight (rt_scene::d_ctr) */
 struct ChunkCtr {
    unsigned long long *next_chain;
    unsigned *tail;
 };
 static ChunkCtr chunk_ctr(const rt_scene *s, int ring)
 {
-   unsigned long long *b = s->d_ctr + 8 * ring;
+   (void)ring;
    ChunkCtr c;
-   c.next_chain = b;
-   c.tail = reinterpret_cast<unsigned *>(b + 2);
+   c.next_chain = s->d_ctr;
+   c.tail = reinterpret_cast<unsigned *>(s->d_ctr + 8 * RT_FETCH_STREAMS);
    return c;
 }
 
@@ -1625,7 +1666,10 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
 
       /* one arena slice per chunk in flight, sized for the largest chunk */
       const long long np_max = chunk_tiles * per_tile;
-      long long cap_ll = (long long)((double)np_max * F) + 64;
+      /* beside the entries the bounce rays need, every wave of the launch may leave one reserved range partly unused */
+      const long long launch_waves = (np_max + RT_BLOCK - 1) / RT_BLOCK < s->trace_blocks ? (np_max + RT_BLOCK - 1) / RT_BLOCK * (RT_BLOCK / 64)
+                                                                                           : (long long)s->trace_blocks * (RT_BLOCK / 64);
+      long long cap_ll = (long long)((double)np_max * F) + (max_rec > 1 ? launch_waves * (long long)s->reserve : 0) + 64;
       if (cap_ll > 0x7fffffffLL / (L > 0 ? L : 1)) { rt_set_error("ray queue too large"); return RT_ERR_TOO_LARGE; }
       const unsigned cap = (unsigned)cap_ll;
       size_t used = 0;
@@ -1643,9 +1687,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
 
       /* tile start order: only for a frame that is one launch, and from a frame of the same geometry */
       const long long key[6] = {p->width, p->height, p->sample_count, tile_first, tile_stride, n_sel};
-      static int use_order = -1;
-      if (use_order < 0) { const char *e = getenv("RT_TILE_ORDER"); use_order = e ? atoi(e) : 1; }
-      const bool track_cost = use_order && n_chunks == 1 && view != VIEW_PRIMARY && max_rec > 1 && per_tile % 64 == 0;
+      const bool track_cost = s->use_tile_order && n_chunks == 1 && view != VIEW_PRIMARY && max_rec > 1 && per_tile % 64 == 0;
       if (track_cost && n_sel > s->order_cap) {
          if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
          if (s->d_tile_order) (void)hipFree(s->d_tile_order);
@@ -1681,9 +1723,9 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          {
             /* counters to zero, spawned rays appended behind the primaries, tile costs and (first chunk) statistics cleared */
             const int n_stats = c == 0 ? ST_COUNT * RT_STAT_REPL : 0, n_cost = track_cost ? (int)n_sel : 0;
-            const int n_init = n_stats > n_cost ? (n_stats > 8 ? n_stats : 8) : (n_cost > 8 ? n_cost : 8);
+            const int n_init = n_stats > n_cost ? (n_stats > RT_CTR_WORDS ? n_stats : RT_CTR_WORDS) : (n_cost > RT_CTR_WORDS ? n_cost : RT_CTR_WORDS);
             hipLaunchKernelGGL(k_begin_chunk, dim3(grid_for(n_init)), dim3(RT_BLOCK), 0, S, c == 0 ? s->d_stats : (unsigned long long *)nullptr,
-                               n_stats, s->d_ctr + 8 * r, ctr.tail, (unsigned)np, track_cost ? s->d_tile_cost : (unsigned *)nullptr, n_cost);
+                               n_stats, s->d_ctr, ctr.tail, (unsigned)np, track_cost ? s->d_tile_cost : (unsigned *)nullptr, n_cost);
             TraceArgs a; memset(&a, 0, sizeof a);
             a.rays = queue; a.n = (unsigned long long)np; a.hits = hits; a.next = ctr.next_chain;
             a.flags = AT(unsigned char, r, o_flags);
@@ -1710,8 +1752,8 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          {
             Timer &tm = ev.begin(S, &st.ms_light);
             hipLaunchKernelGGL(k_light, dim3(grid_for(cap)), dim3(RT_BLOCK), 0, S, sc, (const QRay *)queue, (const Hit *)hits,
-                               (const unsigned char *)AT(unsigned char, r, o_flags), (const unsigned *)ctr.tail, cap, (unsigned)np,
-                               p->shading, AT(float, r, o_totals), s->d_stats);
+                               (const unsigned char *)AT(unsigned char, r, o_flags), (const unsigned *)ctr.tail, cap,
+                               p->shading, AT(float, r, o_totals));
             ev.end(tm, S);
             Timer &tc = ev.begin(S, &st.ms_combine);
             hipLaunchKernelGGL(k_combine_tree, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, (const SpawnRec *)recs,
@@ -1741,8 +1783,9 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       HIP_TRY(hipGetLastError());
       ev.collect();
       if (sum_stat(s->h_stats, ST_ABORTED) != 0) { rt_set_error("traversal aborted: step cap reached (corrupt scene?)"); return RT_ERR_HIP; }
-      /* queue entries per primary the largest chunk wanted, in sixteenths */
-      double wanted = (double)s->h_stats[ST_NODES_PER_PRIMARY_X16 * RT_STAT_REPL] / 16.0;
+      /* queue entries per primary the frame wanted (its chunks taken together) */
+      const double all_slots = (double)n_sel * (double)per_tile;
+      double wanted = (all_slots + (double)sum_stat(s->h_stats, ST_REFLECT) + (double)sum_stat(s->h_stats, ST_REFRACT)) / all_slots;
       if (sum_stat(s->h_stats, ST_LIST_OVERFLOW) != 0) {
          /* a wave's list of spawned rays was full and some were dropped: longer lists, and the frame again */
          if (attempt >= 8 || s->list_cap >= RT_LIST_CAP_MAX) { rt_set_error("spawn list overflow persists at %u entries per wave", s->list_cap); return RT_ERR_TOO_LARGE; }
@@ -1923,7 +1966,7 @@ extern "C" int rt_trace_rays(const rt_scene *cs, int64_t n, const float *rays_ho
    if (rc == RT_OK) {
       (void)hipMemcpy(d_q, q.data(), sizeof(QRay) * (size_t)n, hipMemcpyHostToDevice);
       (void)hipMemset(s->d_stats, 0, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long));
-      (void)hipMemset(s->d_ctr, 0, 8 * sizeof(unsigned long long));
+      (void)hipMemset(s->d_ctr, 0, RT_CTR_WORDS * sizeof(unsigned long long));
       TraceArgs a; memset(&a, 0, sizeof a);
       a.rays = d_q; a.n = (unsigned long long)n; a.hits = d_h; a.next = s->d_ctr;
       launch_trace(s, OUT_HIT, false, a, (unsigned long long)n, lds_bytes, 0);

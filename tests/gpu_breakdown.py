@@ -1,0 +1,53 @@
+"""Ad-hoc (not a test): per-kernel device time and traversal counters of the benchmark frames on one GPU.
+
+    python tests/gpu_breakdown.py [bunny|balls2|all]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracer_amd as ra
+from raytracer_amd import abi
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes")
+
+CASES = {
+    "bunny": ("bunny", 1920, 1080, 4, abi.RT_COOK_TORRANCE),
+    "bunny_obj": ("bunny_obj", 1920, 1080, 4, abi.RT_COOK_TORRANCE),
+    "balls2": ("balls2", 1920, 1080, 1, abi.RT_PHONG),
+    "dragon": ("dragon_large_tris", 1920, 1080, 1, abi.RT_PHONG),
+}
+
+
+def run(name):
+    scene, w, h, spp, shading = CASES[name]
+    sd = ra.SceneData.load(os.path.join(G, scene + ".npz"))
+    with ra.Scene(sd) as sc:
+        best = None
+        for i in range(6):
+            _, st = sc.render(w, h, spp, shading, abi.RT_JITTER_HASH)
+            if i >= 2 and (best is None or st["ms_total"] < best["ms_total"]):
+                best = st
+    with ra.Scene(sd, counters=True) as sc:
+        for i in range(2):
+            _, ct = sc.render(w, h, spp, shading, abi.RT_JITTER_HASH)
+    st = best
+    nv = ct["node_visits"] + ct["node_visits_shadow"]
+    npt = ct["prim_tests"] + ct["prim_tests_shadow"]
+    print(f"{name}: {w}x{h} spp{spp}: total {st['ms_total']:.3f} ms = trace {st['ms_trace']:.3f} + light {st['ms_light']:.3f} + combine "
+          f"{st['ms_combine']:.3f} + resolve {st['ms_resolve']:.3f}; rays {st['rays_total'] / 1e6:.2f} M (primary {st['rays_primary'] / 1e6:.2f}, "
+          f"shadow {st['rays_shadow'] / 1e6:.2f}, bounce {(st['rays_reflect'] + st['rays_refract']) / 1e6:.2f}) -> "
+          f"{st['rays_total'] / st['ms_total'] / 1e3:.0f} Mrays/s", flush=True)
+    print(f"   counted: trace {ct['ms_trace']:.3f} ms, node visits/ray {nv / ct['rays_total']:.1f}, prim tests/ray {npt / ct['rays_total']:.2f}, "
+          f"node-step lane util {nv / max(1, 64 * ct['wave_node_steps']):.3f}, leaf-step util {npt / max(1, 64 * ct['wave_leaf_steps']):.3f}, "
+          f"wave node steps {ct['wave_node_steps'] / 1e6:.2f} M, leaf steps {ct['wave_leaf_steps'] / 1e6:.2f} M, "
+          f"exit mean {ct['wave_exit_mean_ms']:.3f} last {ct['wave_exit_last_ms']:.3f} ms, max list {ct['max_spawn_list']}, "
+          f"attempts {ct['attempts']}", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["bunny", "balls2"]
+    if which == ["all"]:
+        which = list(CASES)
+    for n in which:
+        run(n)
