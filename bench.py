@@ -1,27 +1,35 @@
 #!/usr/bin/env python3
-"""Benchmark of the render path: Mrays/s (primary + secondary) on balls2 at 1920x1080, Phong.
+"""Benchmark of the render path: Mrays/s (primary + secondary) and ms/frame of the bunny frame at 1920x1080.
 
     python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-A step is one frame: one persistent traversal launch (primaries, bounces, shadow feelers) -> light sums -> combine -> resolve,
-with the scene and BVH already resident in HBM and the 8-bit frame left in HBM.  With N > 1 (one
-process per GPU, launched by torch.distributed.run) the frame is sharded by 32x32-pixel tiles, tile k
-to rank k mod N, the scene is replicated, and the compact tile buffers are gathered to rank 0 over
-RCCL and un-tiled there.  The gather of frame k overlaps the rendering of frame k + 1 (two part buffers);
-all K gathers and un-tiles complete inside the timed region.  value = rays of the whole frame
-/ max-over-ranks time.
+Headline workload: the frame the metric names -- bunny_tasty.pov at 1920x1080, Cook-Torrance, 4x stratified
+anti-aliasing (2x2 strata per pixel, hash jitter).  That scene file is not available, so the frame is rendered
+on the reference's own bunny.pov (10 000 flat triangles, one light), the reference tree, every ray traced.
 
-  --scaling weak (default)  the frame grows with N so that every GPU keeps a 1080p frame's worth of
-                            pixels of the same view: 1920x1080, 3840x1080, 3840x2160, 7680x2160 for
-                            N = 1, 2, 4, 8 (same camera, denser sampling of the same frustum)
+A step is one frame: one persistent traversal launch (primaries, bounces, shadow feelers) -> light sums ->
+combine -> resolve, with the scene and BVH already resident in HBM and the 8-bit frame left in HBM.
+`value` = rays of the frame / wall time per frame, `ms_per_step` = ms per frame.  With N > 1 (one process per
+GPU, launched by torch.distributed.run) the frame is sharded by 32x32-pixel tiles, tile k to rank k mod N,
+the scene is replicated, and the compact tile buffers are gathered to rank 0 over RCCL and un-tiled there.
+The gather of frame k overlaps the rendering of frame k + 1 (two part buffers); all K gathers and un-tiles
+complete inside the timed region.
+
+  --scaling weak (default)  the frame grows with N so that every GPU keeps a 1080p frame's worth of pixels of
+                            the same view: 1920x1080, 3840x1080, 3840x2160, 7680x2160 for N = 1, 2, 4, 8
   --scaling strong          the 1920x1080 frame is split N ways
 
-Two extra objects ride on the JSON line:
-  roofline      algorithmic bytes per launch of the dominant kernel (the persistent traversal kernel that
-                traces every ray of the frame) divided by its average launch duration, measured with HIP
-                events on the stream the kernel runs on
-  cpu_baseline  the CPU oracle (a port of the reference's per-pixel logic) timed on this box's host
-                cores on one full frame of the same workload (rank 0, N = 1 only)
+Objects that ride on the JSON line (rank 0; all but `roofline` and `valu` at N = 1 only):
+  roofline      the dominant kernel (the persistent traversal kernel): algorithmic bytes per launch / its average
+                launch duration (HIP events on the stream it runs on), against the ceiling of the memory level
+                that serves those bytes: the XCDs' L2 while scene + BVH fit it, HBM otherwise
+  valu          the same kernel against the vector ALU: wave-instructions per launch (from the committed
+                counter pass of this command) / (SIMDs x issue rate), and the algorithmic flop-equivalents
+  cpu_baseline  the CPU oracle (a port of the reference's per-pixel logic) on this box's host cores, same frame
+  secondary     balls2.pov 1920x1080 Phong (shadows + reflections) and the 1M-triangle / 256-light frame at
+                3840x2160, 16 spp (opt-in surface-area tree; the reference's tree needs ~10^4 box tests per ray there)
+  end_to_end    wall time of one cold launch_kernel-style call (host BVH build, upload, first frame, copy
+                back, free) at 800x600, beside the reference's published whole-program times
 """
 import argparse
 import json
@@ -36,11 +44,20 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 import numpy as np  # noqa: E402
 
-WIDTH, HEIGHT, SAMPLES = 1920, 1080, 1
-SCENE = "balls2"
+WIDTH, HEIGHT, SAMPLES = 1920, 1080, 4
+SCENE = "bunny"
+WORKLOAD = ("bunny_tasty.pov 1920x1080 Cook-Torrance, 4x stratified AA (2x2 strata, hash jitter); the scene file is absent, "
+            "rendered on stand-in A: the reference's bunny.pov (10 000 triangles, 1 light), reference BVH, depth 6")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, GB/s
 L2_PEAK_GBS = 34500.0          # aggregate L2 bandwidth of the 8 XCDs, GB/s
+L2_BYTES_PER_XCD = 4 << 20
+SIMDS = 256 * 4
+VALU_ISSUE_PER_SIMD = 1.2e9    # one wave64 f32 instruction per 2 cycles at 2.4 GHz
+FP32_PEAK_TFLOPS = 78.6        # non-packed f32 FMA peak (half the 157.3 TFLOP/s packed figure)
 WEAK_FRAMES = {1: (1920, 1080), 2: (3840, 1080), 4: (3840, 2160), 8: (7680, 2160)}
+DOMINANT = "k_trace<2, false>"
+PROFILE_TAG = "r02"
+README_WALL_S = {"dragon_large_tris": 1.230, "balls2": 1.875}    # the reference's README:30-40, whole program, unnamed sm_20 GPU
 
 
 def frame_size(world, scaling):
@@ -61,30 +78,107 @@ def algorithmic_bytes(stats):
     return extend, shadow
 
 
-def cpu_baseline(sd, shading, jitter):
+def algorithmic_flops(stats, shading, n_lights):
+    """Flop-equivalents of the same work: 60 per box test (two per node record; a division counts 6), 90 per
+    primitive test, 40 per ray, and per light per shade node 80 (Phong) or 140 (Cook-Torrance)."""
+    import raytracer_amd as ra
+    visits = stats["node_visits"] + stats["node_visits_shadow"]
+    tests = stats["prim_tests"] + stats["prim_tests_shadow"]
+    per_light = 140 if shading == ra.COOK_TORRANCE else 80
+    return 60 * 2 * visits + 90 * tests + 40 * stats["rays_total"] + per_light * n_lights * stats["shade_nodes"]
+
+
+def cpu_baseline(sd, width, height, samples, shading, jitter):
     """The oracle on the host cores: one full frame of the same workload, OpenMP over rows."""
     import orclib
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", "16") or 16), 16))
     osc = orclib.OracleScene(sd)
     t0 = time.perf_counter()
-    r = osc.render(WIDTH, HEIGHT, SAMPLES, shading, jitter, 0, 0, cores, want_samples=False, want_primary=False)
+    r = osc.render(width, height, samples, shading, jitter, 0, 0, cores, want_samples=False, want_primary=False)
     dt = time.perf_counter() - t0
     c = r["counters"]
     rays = c["rays_primary"] + c["rays_shadow"] + c["rays_reflect"] + c["rays_refract"]
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"one whole {SCENE} {WIDTH}x{HEIGHT} frame: {rays} rays in {dt:.2f} s wall on {cores} threads "
+            "ms_per_frame": round(dt * 1e3, 1),
+            "sample": f"one whole {SCENE} {width}x{height} frame at {samples} spp: {rays} rays in {dt:.2f} s wall on {cores} threads "
                       f"({dt * cores:.0f} core-seconds), OpenMP dynamic over rows"}
+
+
+def profile_counter(pas, counter):
+    """Per-launch value of a counter of the dominant kernel from the committed counter passes of this command."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_summary.json")
+    try:
+        return json.load(open(path))[pas][DOMINANT][counter]["per_launch"]
+    except Exception:
+        return None
+
+
+def best_of(scene, params, out_ptr, stream, frames):
+    best = None
+    for _ in range(frames):
+        st = scene.render_device(params, out_ptr, stream)
+        if best is None or st["ms_total"] < best["ms_total"]:
+            best = st
+    return best
+
+
+def secondary_frames(ra, abi, torch, stream):
+    """Frames of the other single-GPU configurations, outside the timed region: steady state, best of a few."""
+    from raytracer_amd import synth
+    out = {}
+    sd = ra.SceneData.load(os.path.join(ROOT, "tests", "golden", "scenes", "balls2.npz"))
+    buf = torch.zeros(3840 * 2160 * 4, dtype=torch.uint8, device="cuda")
+    with ra.Scene(sd, device=0) as sc:
+        p = ra.make_params(1920, 1080, 1, ra.PHONG, abi.RT_JITTER_HASH)
+        for _ in range(3):
+            sc.render_device(p, buf.data_ptr(), stream)
+        st = best_of(sc, p, buf.data_ptr(), stream, 8)
+    out["balls2_1080p"] = {"workload": "balls2.pov 1920x1080 Phong, 1 spp, shadows + reflections, reference BVH",
+                           "ms_per_frame": round(st["ms_total"], 3), "Mrays_per_s": round(st["rays_total"] / st["ms_total"] / 1e3, 1),
+                           "rays_per_frame": st["rays_total"]}
+    t0 = time.perf_counter()
+    big = synth.terrain(1000, 500)
+    with ra.Scene(big, device=0, fast_bvh=True) as sc:
+        info = sc.info()
+        p = ra.make_params(3840, 2160, 16, ra.PHONG, abi.RT_JITTER_HASH)
+        first = sc.render_device(p, buf.data_ptr(), stream)
+        st = sc.render_device(p, buf.data_ptr(), stream)
+    out["terrain_1M_256_lights_4k_16spp"] = {
+        "workload": "1 000 000 procedural triangles, 256 point lights, 3840x2160, 16 spp, Phong; surface-area tree "
+                    "(RT_SCENE_FAST_BVH, outside the parity claim: the reference's tree needs ~10^4 box tests per ray on this scene)",
+        "ms_per_frame": round(st["ms_total"], 1), "first_frame_ms": round(first["ms_total"], 1),
+        "Mrays_per_s": round(st["rays_total"] / st["ms_total"] / 1e3, 1), "rays_per_frame": st["rays_total"],
+        "launches_per_frame": st["launches_trace"], "host_tree_build_ms": round(info["ms_build_host"], 0),
+        "wall_s_incl_scene_generation_and_build": round(time.perf_counter() - t0, 1)}
+    return out
+
+
+def end_to_end(ra, abi, first_ms, steady_ms):
+    """One cold call in the shape of launch_kernel (kernel.cu:689-761): scene construction with the host BVH build,
+    upload, first frame, copy back, free -- wall clock, at the reference's default 800x600, 1 spp, Phong."""
+    out = {"headline_first_frame_ms": round(first_ms, 3), "headline_steady_frame_ms": round(steady_ms, 3), "cold_call_800x600": {}}
+    for name in ("balls2", "dragon_large_tris"):
+        sd = ra.SceneData.load(os.path.join(ROOT, "tests", "golden", "scenes", name + ".npz"))
+        frame = np.zeros(800 * 600 * 4, np.uint8)
+        t0 = time.perf_counter()
+        ra.launch_kernel(sd, ra.PHONG, 800, 600, frame, 1)
+        dt = time.perf_counter() - t0
+        out["cold_call_800x600"][name] = {"wall_ms": round(dt * 1e3, 2),
+                                          "reference_whole_program_s": README_WALL_S[name],
+                                          "note": "reference figure: `time ./raytrace` incl. parse + TGA on an unnamed sm_20 GPU (README:30-40); context, not a like-for-like baseline"}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fast-bvh", action="store_true", help="skip the informational fast-tree frames (keeps a profile of this command to the benchmark's own launches)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other configurations' frames, the fast-tree frame and the cold-call timing "
+                                                                "(keeps a profile of this command to the benchmark's own launches)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks share cuda:0 and exchange over gloo (host-staged): checks the N > 1 code path on a 1-GPU box")
     args = ap.parse_args()
@@ -114,7 +208,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     sd = ra.SceneData.load(os.path.join(ROOT, "tests", "golden", "scenes", SCENE + ".npz"))
-    shading, jitter = ra.PHONG, abi.RT_JITTER_HASH
+    shading, jitter = ra.COOK_TORRANCE, abi.RT_JITTER_HASH
     scene = ra.Scene(sd, device=local_rank)
 
     width, height = frame_size(world, args.scaling)
@@ -159,8 +253,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    first_ms = None
     for _ in range(args.warmup):
+        tw = time.perf_counter()
         step()
+        if first_ms is None:
+            torch.cuda.synchronize()
+            first_ms = (time.perf_counter() - tw) * 1e3      # the scene's first frame: no tile order yet, queues still to be sized
     fence()
     t0 = time.perf_counter()
     acc = {}
@@ -183,12 +282,11 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = rays[0] * args.steps / dt / 1e6
 
-    roofline = None
-    baseline = None
-    fast_mode = None
+    roofline = valu = baseline = secondary = e2e = None
     if rank == 0:
         # algorithmic bytes of the dominant kernel: one counted frame on the same tiles (outside the timed region)
         counted = ra.Scene(sd, device=local_rank, counters=True)
+        info = counted.info()
         buf = part if world > 1 else frame
         cst = counted.render_device(params, buf.data_ptr(), stream)
         counted.close()
@@ -198,49 +296,54 @@ def main():
         avg_ms = acc["ms_trace"] / args.steps / launches
         bytes_per_launch = (b_extend + b_shadow) / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        in_l2 = info["device_bytes"] <= L2_BYTES_PER_XCD
+        peak = L2_PEAK_GBS if in_l2 else HBM_PEAK_GBS
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_trace_kernel.json")
         if os.path.exists(tpath) and world == 1:
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch") if tj.get("tag") == PROFILE_TAG else None
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_trace<OUT_CHAIN>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 4),
-                    "launches_per_step": launches,
+        roofline = {"bound": "hbm", "level": "l2" if in_l2 else "hbm", "kernel": "k_trace<OUT_CHAIN>",
+                    "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches,
                     "bytes_closest_hit_rays": int(b_extend), "bytes_shadow_rays": int(b_shadow),
-                    "l2_peak": L2_PEAK_GBS, "frac_of_l2_peak": round(achieved / L2_PEAK_GBS, 4),
-                    "note": "scene + BVH are 1.3 MB and stay in L2, so the algorithmic bytes (one 64-byte record per node "
-                            "visit) are served by L2 and can exceed the HBM peak; measured HBM-side traffic is `traffic`. "
-                            "What bounds the kernel is each wave's own dependent chain (about 130 instructions and one record "
-                            "fetch per traversal step) at the 4 waves per SIMD that 128 registers allow, not bandwidth"}
+                    "scene_bytes": int(info["device_bytes"]), "hbm_peak": HBM_PEAK_GBS,
+                    "note": ("memory-bound kernel; scene + BVH (%.1f MB) fit each XCD's 4 MiB L2, so the algorithmic bytes (one 64-byte record "
+                             "per node visit) are served by L2 and `peak` is the aggregate L2 bandwidth; `traffic` is the measured "
+                             "HBM-side bytes per launch" % (info["device_bytes"] / 1e6)) if in_l2 else
+                            "scene + BVH exceed the XCDs' L2: `peak` is the HBM bandwidth"}
+        insts = profile_counter("pmc_sq", "SQ_INSTS_VALU") if world == 1 else None
+        flops = algorithmic_flops(cst, shading, len(sd.lights)) / launches
+        valu = {"kernel": "k_trace<OUT_CHAIN>", "wave_insts_per_launch": insts,
+                "issue_peak_per_s": SIMDS * VALU_ISSUE_PER_SIMD,
+                "frac": round(insts / (avg_ms * 1e-3) / (SIMDS * VALU_ISSUE_PER_SIMD), 4) if insts else None,
+                "flop_equiv_per_launch": int(flops), "achieved_tflops_equiv": round(flops / (avg_ms * 1e-3) / 1e12, 2),
+                "peak_tflops": FP32_PEAK_TFLOPS, "frac_flop_equiv": round(flops / (avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                "lane_utilisation_node_steps": round((cst["node_visits"] + cst["node_visits_shadow"]) / max(1, 64 * cst["wave_node_steps"]), 3),
+                "lane_utilisation_leaf_steps": round((cst["prim_tests"] + cst["prim_tests_shadow"]) / max(1, 64 * cst["wave_leaf_steps"]), 3),
+                "note": "wave_insts_per_launch = SQ_INSTS_VALU of the committed counter pass of this command (profiles/); "
+                        "issue peak = 1 024 SIMDs x one wave64 instruction per 2 cycles at 2.4 GHz"}
         if world == 1 and not args.no_cpu_baseline:
-            baseline = cpu_baseline(sd, shading, jitter)
-        if world == 1 and not args.no_fast_bvh:
-            # informational only: the same frame with the opt-in SAH tree (not the reference's tree, not a parity mode)
-            fscene = ra.Scene(sd, device=local_rank, fast_bvh=True)
-            best = None
-            for _ in range(4):
-                fst = fscene.render_device(params, frame.data_ptr(), stream)
-                best = fst if best is None or fst["ms_total"] < best["ms_total"] else best
-            fscene.close()
-            fast_mode = {"value": round(best["rays_total"] / best["ms_total"] / 1e3, 1), "unit": "Mrays/s",
-                         "ms_per_frame": round(best["ms_total"], 3),
-                         "note": "RT_SCENE_FAST_BVH: another tree over the same primitives; near-tie outcomes differ from "
-                                 "the reference's, so this is outside the parity claim and is not `value`"}
+            baseline = cpu_baseline(sd, width, height, SAMPLES, shading, jitter)
+        if world == 1 and not args.no_secondary:
+            secondary = secondary_frames(ra, abi, torch, stream)
+            e2e = end_to_end(ra, abi, first_ms if first_ms is not None else 0.0, acc["ms_total"] / args.steps)
 
     if rank == 0:
         out = {
-            "metric": "Mrays/s (primary+secondary)", "value": round(value, 2), "unit": "Mrays/s",
+            "metric": "Mrays/s (primary+secondary); ms/frame bunny_tasty 1080p", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "ms_per_frame": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{SCENE}.pov {width}x{height} Phong, {SAMPLES} spp, shadows + reflections, depth 6",
-                       "per_gpu": f"{width * height // world} pixels",
+            "config": {"workload": WORKLOAD if (width, height) == (WIDTH, HEIGHT) else WORKLOAD.replace("1920x1080", f"{width}x{height}"),
+                       "per_gpu": f"{width * height // world} pixels x {SAMPLES} samples",
                        "rays_per_frame": int(rays[0]), "primary": int(rays[1]), "shadow": int(rays[2]), "bounce": int(rays[3]),
                        "parallelism": f"tiles{world}", "tile": abi.RT_TILE, "jitter": "hash"},
             "device_ms_per_step": {k: round(v / args.steps, 4) for k, v in acc.items()},
-            "roofline": roofline, "cpu_baseline": baseline, "fast_bvh_mode": fast_mode,
+            "roofline": roofline, "valu": valu, "cpu_baseline": baseline, "secondary": secondary, "end_to_end": e2e,
         }
         print(json.dumps(out))
     if world > 1:

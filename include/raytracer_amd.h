@@ -164,6 +164,13 @@ typedef struct rt_stats {
    /* wave-level step counts (one per wave per executed node step / leaf step): lane utilisation of
     * the traversal loop = (node_visits + node_visits_shadow) / (64 * wave_node_steps) */
    uint64_t wave_node_steps, wave_leaf_steps;
+   /* where the other lanes of a node step were: waiting at a leaf for the wave's next leaf step, or without a ray
+    * (waiting for the wave's next refill); and how many refills the waves made */
+   uint64_t lane_steps_at_leaf, lane_steps_no_ray, wave_refills;
+   /* shares of the waves' lifetime spent in refills (spawning bounce rays, starting new rays), in node steps and
+    * in leaf steps */
+   float wave_time_refill, wave_time_node, wave_time_leaf;
+   int32_t pad0;
    /* the longest single ray, in wave steps it was in flight */
    uint64_t max_ray_steps;
    /* most spawned rays / shadow items any wave held back at once (always filled); a frame that overflows the

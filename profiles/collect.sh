@@ -6,18 +6,18 @@
 #   3. separate --pmc passes: FETCH_SIZE, WRITE_SIZE (HBM-side bytes), SQ busy/wait counters, L2 hit/miss
 # Raw output lands in gpurun_out/prof_<tag>/; profiles/summarize.py condenses it into profiles/<tag>_*.
 set -e -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 REPO=$(pwd)
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 10 --warmup 3"
+BENCH="python3 $REPO/bench.py --steps 20 --warmup 3"
 timeout -k 10 300 $BENCH > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/kt -o kt -- $BENCH --no-cpu-baseline --no-fast-bvh > $REPO/$OUT/kt.log 2>&1
-timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o pmc -- $BENCH --no-cpu-baseline --no-fast-bvh > $REPO/$OUT/pmc_fetch.log 2>&1
-timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o pmc -- $BENCH --no-cpu-baseline --no-fast-bvh > $REPO/$OUT/pmc_write.log 2>&1
-timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $REPO/$OUT/pmc_sq -o pmc -- $BENCH --no-cpu-baseline --no-fast-bvh > $REPO/$OUT/pmc_sq.log 2>&1
-timeout -s KILL 240 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $REPO/$OUT/pmc_l2 -o pmc -- $BENCH --no-cpu-baseline --no-fast-bvh > $REPO/$OUT/pmc_l2.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/kt -o kt -- $BENCH --no-cpu-baseline --no-secondary > $REPO/$OUT/kt.log 2>&1
+timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $REPO/$OUT/pmc_fetch -o pmc -- $BENCH --no-cpu-baseline --no-secondary > $REPO/$OUT/pmc_fetch.log 2>&1
+timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $REPO/$OUT/pmc_write -o pmc -- $BENCH --no-cpu-baseline --no-secondary > $REPO/$OUT/pmc_write.log 2>&1
+timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $REPO/$OUT/pmc_sq -o pmc -- $BENCH --no-cpu-baseline --no-secondary > $REPO/$OUT/pmc_sq.log 2>&1
+timeout -s KILL 240 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $REPO/$OUT/pmc_l2 -o pmc -- $BENCH --no-cpu-baseline --no-secondary > $REPO/$OUT/pmc_l2.log 2>&1
 cd $REPO
 python3 profiles/summarize.py $TAG

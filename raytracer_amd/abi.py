@@ -91,6 +91,8 @@ class Stats(C.Structure):
                 ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64), ("tie_events", C.c_uint64),
                 ("node_visits_shadow", C.c_uint64), ("prim_tests_shadow", C.c_uint64), ("tie_events_shadow", C.c_uint64),
                 ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64),
+                ("lane_steps_at_leaf", C.c_uint64), ("lane_steps_no_ray", C.c_uint64), ("wave_refills", C.c_uint64),
+                ("wave_time_refill", C.c_float), ("wave_time_node", C.c_float), ("wave_time_leaf", C.c_float), ("pad0", C.c_int32),
                 ("max_ray_steps", C.c_uint64), ("max_spawn_list", C.c_uint64)]
 
     def as_dict(self):

@@ -91,7 +91,7 @@ struct SpawnRec {
 
 enum { ST_SHADOW_SKIPPED = 0, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES,
        ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
-       ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW,
+       ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_LEAF_WAIT, ST_NO_RAY, ST_REFILLS, ST_CLK_REFILL, ST_CLK_NODE, ST_CLK_LEAF, ST_CLK_WAVE,
        ST_ABORTED, ST_MAX_RAY_STEPS, ST_MAX_LIST, ST_OVERFLOW, ST_LIST_OVERFLOW,
        ST_CLOCK_FIRST_START, ST_CLOCK_LAST_EXIT, ST_CLOCK_EXIT_SUM, ST_WAVES,
 #ifdef RT_DEBUG_EXIT_HIST
@@ -506,6 +506,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    unsigned nv = 0, np = 0, nt = 0, wn = 0, wl = 0;
    unsigned nvs = 0, nps = 0, nts = 0;                       /* COUNT only: the same for shadow feelers */
    unsigned ray_steps = 0, max_ray_steps = 0;   /* COUNT only: wave steps this ray has been in flight */
+   unsigned long long clk_refill = 0, clk_node = 0, clk_leaf = 0;   /* COUNT only: 100 MHz ticks this wave spent in each part of its loop */
+   unsigned n_leafwait = 0, n_noray = 0, n_refills = 0;   /* COUNT only: node steps this lane sat out at a leaf / without a ray; refills of the wave */
 
    /* a ray is finished: scan the planes unless it left early, write its result */
    auto finish = [&](bool early) {
@@ -667,7 +669,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       int n_idle = 64 - __popcll(m_active);
       bool any_pend = OUT == OUT_CHAIN && __ballot(pend) != 0;
       if ((n_idle >= a.refill_idle || m_active == 0) && (!exhausted || list_count > 0 || any_pend)) {
+         const unsigned long long clk0 = COUNT ? wall_clock64() : 0ULL;
          if (any_pend) spawn_stage();
+         if (COUNT) n_refills++;
          unsigned long long m_idle = ~m_active;
          int rank = __popcll(m_idle & below);
          int take = 0;
@@ -785,6 +789,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          m_active = __ballot(active);
          wave_par = __ballot(active && c.par != 0) != 0;
          wave_lit = __ballot(active && !c.fast) != 0;
+         if (COUNT) clk_refill += wall_clock64() - clk0;
       }
       if (m_active == 0) {
          if (exhausted && list_count == 0 && !(OUT == OUT_CHAIN && __ballot(pend) != 0)) break;
@@ -797,13 +802,19 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          for (int burst = 0; burst < a.node_burst; burst++) {
             bool in_node = cur >= 0;                 /* idle lanes hold RT_CUR_IDLE */
             if (__ballot(in_node) == 0) break;
-            if (COUNT) { wn++; if (active) ray_steps++; }
+            if (COUNT) {
+               wn++; if (active) ray_steps++;
+               if (cur < 0) { if (cur == RT_CUR_IDLE) n_noray++; else n_leafwait++; }
+            }
             if (in_node) node_step(variant_tag);
          }
       };
+      const unsigned long long clk1 = COUNT ? wall_clock64() : 0ULL;
       if (wave_lit) burst_loop(std::integral_constant<int, 2>());
       else if (wave_par) burst_loop(std::integral_constant<int, 1>());
       else burst_loop(std::integral_constant<int, 0>());
+      const unsigned long long clk2 = COUNT ? wall_clock64() : 0ULL;
+      if (COUNT) clk_node += clk2 - clk1;
       /* ---- leaf step ---- */
       bool at_leaf = active && cur < 0;
       if (__ballot(at_leaf) != 0) {
@@ -852,6 +863,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             else pop(top);
          }
       }
+      if (COUNT) clk_leaf += wall_clock64() - clk2;
    }
 #ifdef RT_DEBUG_EXIT_HIST
    if (lane == 0) {
@@ -881,7 +893,12 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          stat_add(stats, ST_PRIM_TESTS_SHADOW, (unsigned long long)nps);
          stat_add(stats, ST_TIES_SHADOW, (unsigned long long)nts);
       }
+      stat_add(stats, ST_LEAF_WAIT, (unsigned long long)n_leafwait);
+      stat_add(stats, ST_NO_RAY, (unsigned long long)n_noray);
       if (lane == 0) {
+         stat_add(stats, ST_REFILLS, (unsigned long long)n_refills);
+         stat_add(stats, ST_CLK_REFILL, clk_refill); stat_add(stats, ST_CLK_NODE, clk_node); stat_add(stats, ST_CLK_LEAF, clk_leaf);
+         stat_add(stats, ST_CLK_WAVE, wall_clock64() - clock_start);
          stat_add(stats, ST_WAVE_NODE_STEPS, (unsigned long long)wn);
          stat_add(stats, ST_WAVE_LEAF_STEPS, (unsigned long long)wl);
       }
@@ -1843,6 +1860,14 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    st.node_visits_shadow = sum_stat(s->h_stats, ST_NODE_VISITS_SHADOW); st.prim_tests_shadow = sum_stat(s->h_stats, ST_PRIM_TESTS_SHADOW);
    st.tie_events_shadow = sum_stat(s->h_stats, ST_TIES_SHADOW);
    st.wave_node_steps = sum_stat(s->h_stats, ST_WAVE_NODE_STEPS); st.wave_leaf_steps = sum_stat(s->h_stats, ST_WAVE_LEAF_STEPS);
+   st.lane_steps_at_leaf = sum_stat(s->h_stats, ST_LEAF_WAIT); st.lane_steps_no_ray = sum_stat(s->h_stats, ST_NO_RAY);
+   st.wave_refills = sum_stat(s->h_stats, ST_REFILLS);
+   {
+      double w = (double)sum_stat(s->h_stats, ST_CLK_WAVE);
+      st.wave_time_refill = w > 0 ? (float)((double)sum_stat(s->h_stats, ST_CLK_REFILL) / w) : 0.0f;
+      st.wave_time_node = w > 0 ? (float)((double)sum_stat(s->h_stats, ST_CLK_NODE) / w) : 0.0f;
+      st.wave_time_leaf = w > 0 ? (float)((double)sum_stat(s->h_stats, ST_CLK_LEAF) / w) : 0.0f;
+   }
    st.max_ray_steps = s->h_stats[ST_MAX_RAY_STEPS * RT_STAT_REPL];
    st.max_spawn_list = s->h_stats[ST_MAX_LIST * RT_STAT_REPL];
    st.attempts = attempts;

@@ -43,6 +43,10 @@ def run(name):
           f"wave node steps {ct['wave_node_steps'] / 1e6:.2f} M, leaf steps {ct['wave_leaf_steps'] / 1e6:.2f} M, "
           f"exit mean {ct['wave_exit_mean_ms']:.3f} last {ct['wave_exit_last_ms']:.3f} ms, max list {ct['max_spawn_list']}, "
           f"attempts {ct['attempts']}", flush=True)
+    slots = max(1, 64 * ct["wave_node_steps"])
+    print(f"   node-step lanes: at a leaf {ct['lane_steps_at_leaf'] / slots:.3f}, without a ray {ct['lane_steps_no_ray'] / slots:.3f}; "
+          f"refills {ct['wave_refills'] / 1e3:.1f} k ({ct['rays_total'] / max(1, ct['wave_refills']):.1f} rays per refill); wave time: "
+          f"refill {ct['wave_time_refill']:.3f}, node steps {ct['wave_time_node']:.3f}, leaf steps {ct['wave_time_leaf']:.3f}", flush=True)
 
 
 if __name__ == "__main__":
