@@ -138,19 +138,22 @@ def secondary_frames(ra, abi, torch, stream):
                            "ms_per_frame": round(st["ms_total"], 3), "Mrays_per_s": round(st["rays_total"] / st["ms_total"] / 1e3, 1),
                            "rays_per_frame": st["rays_total"]}
     t0 = time.perf_counter()
-    big = synth.terrain(1000, 500)
-    with ra.Scene(big, device=0, fast_bvh=True) as sc:
-        info = sc.info()
-        p = ra.make_params(3840, 2160, 16, ra.PHONG, abi.RT_JITTER_HASH)
-        first = sc.render_device(p, buf.data_ptr(), stream)
-        st = sc.render_device(p, buf.data_ptr(), stream)
-    out["terrain_1M_256_lights_4k_16spp"] = {
-        "workload": "1 000 000 procedural triangles, 256 point lights, 3840x2160, 16 spp, Phong; surface-area tree "
-                    "(RT_SCENE_FAST_BVH, outside the parity claim: the reference's tree needs ~10^4 box tests per ray on this scene)",
-        "ms_per_frame": round(st["ms_total"], 1), "first_frame_ms": round(first["ms_total"], 1),
-        "Mrays_per_s": round(st["rays_total"] / st["ms_total"] / 1e3, 1), "rays_per_frame": st["rays_total"],
-        "launches_per_frame": st["launches_trace"], "host_tree_build_ms": round(info["ms_build_host"], 0),
-        "wall_s_incl_scene_generation_and_build": round(time.perf_counter() - t0, 1)}
+    label = ("1 000 000 procedural triangles, 256 point lights, 3840x2160, 16 spp, Phong; surface-area tree "
+             "(RT_SCENE_FAST_BVH, outside the parity claim: the reference's tree needs ~10^4 box tests per ray on this scene)")
+    try:
+        big = synth.terrain(1000, 500)
+        with ra.Scene(big, device=0, fast_bvh=True) as sc:
+            info = sc.info()
+            p = ra.make_params(3840, 2160, 16, ra.PHONG, abi.RT_JITTER_HASH)
+            first = sc.render_device(p, buf.data_ptr(), stream)
+            st = sc.render_device(p, buf.data_ptr(), stream)
+        out["terrain_1M_256_lights_4k_16spp"] = {
+            "workload": label, "ms_per_frame": round(st["ms_total"], 1), "first_frame_ms": round(first["ms_total"], 1),
+            "Mrays_per_s": round(st["rays_total"] / st["ms_total"] / 1e3, 1), "rays_per_frame": st["rays_total"],
+            "launches_per_frame": st["launches_trace"], "host_tree_build_ms": round(info["ms_build_host"], 0),
+            "wall_s_incl_scene_generation_and_build": round(time.perf_counter() - t0, 1)}
+    except Exception as e:      # reported, not hidden: the headline above does not depend on this frame
+        out["terrain_1M_256_lights_4k_16spp"] = {"workload": label, "error": str(e)}
     return out
 
 

@@ -31,7 +31,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <deque>
+#include <functional>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -60,6 +62,25 @@ struct DScene {
    int any_xform;    /* some BVH primitive carries a transform */
 };
 
+/* Division of a 32-bit unsigned by a divisor fixed for the launch, without the 30-odd instructions of the general
+ * sequence (Granlund & Montgomery's round-up method): with l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1,
+ * x / d = (mulhi(m, x) + ((x - mulhi(m, x)) >> min(l, 1))) >> max(l - 1, 0) for every x below 2^32 and d >= 1. */
+struct FastDiv { unsigned m, s1, s2; };
+static FastDiv make_fastdiv(unsigned d)
+{
+   unsigned l = 0;
+   while ((1ULL << l) < d) l++;
+   FastDiv f;
+   f.m = (unsigned)((((1ULL << l) - d) << 32) / d + 1ULL);
+   f.s1 = l < 1 ? l : 1; f.s2 = l > 0 ? l - 1 : 0;
+   return f;
+}
+__device__ __forceinline__ unsigned fd_div(unsigned x, FastDiv f)
+{
+   unsigned t1 = __umulhi(f.m, x);
+   return (t1 + ((x - t1) >> f.s1)) >> f.s2;
+}
+
 struct DCamera {
    F3 pos, up, right, look_dir;   /* look_dir = normalize(lookAt - pos), kernel.cu:717-718 */
 };
@@ -74,6 +95,9 @@ struct DGrid {
    int k0;                  /* first selection entry of this batch */
    int ts;                  /* samples per tile edge = RT_TILE*sroot */
    int patches_per_row;     /* ts / 8 */
+   unsigned per_tile;       /* samples of one tile = ts*ts */
+   FastDiv per_tile_div, patches_per_row_div, tiles_x_div;
+   float inv_res_w, inv_res_h;   /* RN(1/res_w), RN(1/res_h): for the exact divisions of the camera rays */
    int jitter; unsigned seed;
 };
 
@@ -265,17 +289,16 @@ __device__ __forceinline__ unsigned hash32(unsigned x)
 
 /* sample slot -> sample coordinates on the (W*s) x (H*s) grid.  A tile's samples are
  * numbered in 8x8 patches so that 64 consecutive slots cover a compact square of the image. */
-__device__ __forceinline__ bool slot_to_sample(const DGrid &g, long long slot, int &X, int &Y)
+__device__ __forceinline__ bool slot_to_sample(const DGrid &g, unsigned slot, int &X, int &Y)
 {
-   int per_tile = g.ts * g.ts;
-   int k = (int)(slot / per_tile);
-   int r = (int)(slot % per_tile);
-   int patch = r >> 6, lane = r & 63;
-   int px = patch % g.patches_per_row, py = patch / g.patches_per_row;
-   int sx = px * 8 + (lane & 7), sy = py * 8 + (lane >> 3);
-   int tile = g.tile_first + (g.k0 + k) * g.tile_stride;
-   int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
-   X = tx * g.ts + sx; Y = ty * g.ts + sy;
+   unsigned k = fd_div(slot, g.per_tile_div);
+   unsigned r = slot - k * g.per_tile;
+   unsigned patch = r >> 6, lane = r & 63;
+   unsigned py = fd_div(patch, g.patches_per_row_div), px = patch - py * (unsigned)g.patches_per_row;
+   int sx = (int)(px * 8 + (lane & 7)), sy = (int)(py * 8 + (lane >> 3));
+   unsigned tile = (unsigned)g.tile_first + ((unsigned)g.k0 + k) * (unsigned)g.tile_stride;
+   unsigned ty = fd_div(tile, g.tiles_x_div), tx = tile - ty * (unsigned)g.tiles_x;
+   X = (int)tx * g.ts + sx; Y = (int)ty * g.ts + sy;
    return X < g.res_w && Y < g.res_h;
 }
 
@@ -290,10 +313,12 @@ __device__ __forceinline__ Ray camera_ray(const DCamera &cam, const DGrid &g, in
       r1 = (float)((h1 >> 8) + 1U) * 5.9604644775390625e-8f;   /* (0, 1], like curand_uniform */
       r2 = (float)((h2 >> 8) + 1U) * 5.9604644775390625e-8f;
    }
-   float uJitter = (r1 - .5f) / (float)g.res_w;
-   float vJitter = (r2 - .5f) / (float)g.res_h;
-   float u = 2.0f * ((float)x / (float)g.res_w) - 1.0f + uJitter;
-   float v = 2.0f * ((float)y / (float)g.res_h) - 1.0f + vJitter;
+   /* the four divisions by the resolution, correctly rounded (rt_div) with the reciprocals the host passes */
+   const float fw = (float)g.res_w, fh = (float)g.res_h;
+   float uJitter = rt_div(r1 - .5f, fw, g.inv_res_w);
+   float vJitter = rt_div(r2 - .5f, fh, g.inv_res_h);
+   float u = 2.0f * rt_div((float)x, fw, g.inv_res_w) - 1.0f + uJitter;
+   float v = 2.0f * rt_div((float)y, fh, g.inv_res_h) - 1.0f + vJitter;
    F3 rPos = (u * .5f) * cam.right + (v * .5f) * cam.up + cam.pos;
    F3 rDir = rPos - cam.pos + cam.look_dir;
    Ray r; r.o = rPos; r.d = rDir;
@@ -344,23 +369,24 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2 };
 #define RT_STEP_CAP (1ULL << 28)
 #define RT_REFILL_IDLE 20   /* pull new rays once this many lanes of the wave are idle */
 #define RT_CUR_IDLE ((int)0x80000000)
-#define RT_TAKE_OLDEST 64    /* lanes of a refill that take the oldest list entries: all of them */
 #define RT_LIST_CAP_FIRST 1024u   /* entries of a wave's list to begin with; doubled when a frame overflows it */
 #define RT_LIST_CAP_MAX 65536u
 #define RT_NODE_BURST 16    /* node steps between two leaf steps / refill checks */
 #define RT_FETCH_STREAMS 64u /* counters the primaries are handed out through */
 #define RT_CTR_WORDS (8 * ((int)RT_FETCH_STREAMS + 1))   /* 64-bit words of a launch's counters: the streams' (64 bytes apart), then the queue tail */
+#define RT_ORDER_CLASSES 64 /* classes of tile cost that decide the order in which a frame's tiles are started */
+#define RT_ORDER_MEAN_WEIGHT 4
 #define RT_RESERVE 256      /* queue entries a wave reserves at a time for the bounce rays it spawns */
 
 struct TraceArgs {
    QRay *rays;                  /* the queue; OUT_CHAIN appends spawned rays behind the first n */
    unsigned long long n;        /* rays to fetch (OUT_CHAIN: the primaries) */
    Hit *hits;
-   unsigned char *flags;        /* OUT_CHAIN: isInShadow of (light k, queue entry i) at flags[k*cap + i] */
+   unsigned *flag_words;        /* OUT_CHAIN: isInShadow of (queue entry i, light k) is bit k%32 of flag_words[i*flag_stride + k/32]; zeroed */
+   unsigned flag_stride;
    unsigned long long *next;    /* this launch's zeroed fetch counters: RT_FETCH_STREAMS of them, 64 bytes apart */
    unsigned long long *stats;
    int refill_idle, node_burst; /* tuning: idle lanes that trigger a refill, node steps between two leaf steps */
-   int take_oldest;             /* lanes of a refill that take the oldest list entries instead of the newest */
    unsigned reserve;            /* OUT_CHAIN: queue entries a wave reserves per atomic for the bounce rays it spawns */
    /* OUT_CHAIN */
    DCamera cam;                 /* the first n entries are the primaries of grid `g`: made here, on fetch */
@@ -370,10 +396,10 @@ struct TraceArgs {
    unsigned *tail;              /* next queue entry no wave has reserved; starts at n */
    unsigned cap;                /* entries the queue has room for */
    int max_rec;
-   unsigned *lists;             /* one ring of list_cap (a power of two) entries per wave of the launch */
+   uint2 *lists;                /* one ring of list_cap (a power of two) entries per wave of the launch: {queue entry | RT_SHADOW_ITEM, light} */
    unsigned list_cap;
    const int *tile_order;       /* when non-null: the order in which the launch's tiles are started (costliest first) */
-   unsigned per_tile;           /* samples of one tile */
+   unsigned *dur;               /* when non-null: per queue entry, how many turns of its wave's loop the closest-hit ray was in flight */
 };
 
 __device__ __forceinline__ QRay load_qray_rec(const QRay *q, unsigned long long i)
@@ -468,12 +494,15 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    /* OUT_CHAIN: this wave's list of spawned rays and shadow items still to be started, a ring of a.list_cap entries in
     * global memory: entries head .. head+count-1 (wave-uniform).  Written with plain stores, read back past the
     * CU's vector cache (the reader is another lane of the same wave, some refills later). */
-   unsigned *const list = a.lists ? a.lists + (size_t)(blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * a.list_cap : nullptr;
+   uint2 *const list = a.lists ? a.lists + (size_t)(blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * a.list_cap : nullptr;
    const int list_mask = (int)a.list_cap - 1;
    int list_peak = 0;
    int list_count = 0, list_head = 0;
-   auto list_put = [&](int k, unsigned v) { list[(list_head + k) & list_mask] = v; };
-   auto list_get = [&](int k) { return __hip_atomic_load(list + ((list_head + k) & list_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+   auto list_put = [&](int k, uint2 v) { *reinterpret_cast<unsigned long long *>(list + ((list_head + k) & list_mask)) = (unsigned long long)v.x | ((unsigned long long)v.y << 32); };
+   auto list_get = [&](int k) {
+      unsigned long long w = __hip_atomic_load(reinterpret_cast<unsigned long long *>(list + ((list_head + k) & list_mask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return make_uint2((unsigned)w, (unsigned)(w >> 32));
+   };
    const unsigned long long n = a.n;
    unsigned long long *const stats = a.stats;
    const unsigned long long clock_start = COUNT ? wall_clock64() : 0ULL;     /* 100 MHz */
@@ -481,6 +510,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    const unsigned long long dbg_start = wall_clock64();
 #endif
 
+   unsigned long long guard = 0;       /* wave-uniform: turns of the loop below */
+   unsigned born = 0;                  /* the turn in which this lane's ray started */
    bool active = false;
    bool pend = false;                  /* OUT_CHAIN: finished, its bounce rays not spawned yet */
    bool exhausted = n == 0;            /* wave-uniform: the queue has no more rays to fetch */
@@ -490,7 +521,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    c.r.o = mk3(0, 0, 0); c.r.d = mk3(1, 1, 1); c.yx = c.yy = c.yz = 1.0f; c.par = 0; c.fast = true;
    float t = FLT_MAX, toBeat = -FLT_MAX;
    int closest = -1, cur = RT_CUR_IDLE, sp = 0, tag = 0;   /* cur: node index, ~primitive, or RT_CUR_IDLE while the lane has no ray */
-   int mode = MODE_EXTEND;             /* OUT_CHAIN: what this lane's ray is */
+   int mode = MODE_EXTEND;             /* OUT_CHAIN: what this lane's ray is; tag: depth level + 1 (closest-hit rays) or the light (feelers) */
    unsigned idx = 0;
    /* Every atomic on a word that all waves of the launch share costs the chip about 12 ns (they are served one
     * after the other, wherever the waves run): 100 000 of them are a millisecond.  So the primaries are handed out
@@ -515,10 +546,15 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       if (!early) plane_scan(sc, c.r, t, closest);
       active = false; cur = RT_CUR_IDLE;
       if (OUT == OUT_CHAIN && mode != MODE_EXTEND) {
-         a.flags[tag - 1] = less_than(t, toBeat) ? 1 : 0;            /* kernel.cu:206 */
+         /* kernel.cu:206; a feeler that is not shadowed leaves its bit as the launch found it: clear */
+         if (less_than(t, toBeat)) atomicOr(a.flag_words + (size_t)idx * a.flag_stride + ((unsigned)tag >> 5), 1u << ((unsigned)tag & 31u));
       } else {
          Hit h; h.prim = closest; h.t = t; a.hits[idx] = h;
-         if (OUT == OUT_CHAIN) pend = true;
+         if (OUT == OUT_CHAIN) {
+            if (a.dur) a.dur[idx] = (unsigned)guard - born;
+            if (closest >= 0) pend = true;
+            else *reinterpret_cast<float4 *>(a.recs + idx) = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));   /* a miss: nothing to spawn */
+         }
       }
    };
    /* The entry a pop would take first, read ahead of the work that decides whether a pop happens: a step either
@@ -592,7 +628,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       BounceRays b;
       SpawnRec out;
       out.refl = out.alpha = 0.0f; out.child_refl = out.child_refr = -1;
-      if (pend && closest >= 0) {
+      if (pend) {
          shaded = true;
          unsigned mat_id = closest < sc.n_prims ? sc.prims[closest].material : sc.planes[closest - sc.n_prims].material;
          const rt_material &m = sc.materials[mat_id];
@@ -639,14 +675,14 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             if (okT) {
                store_qray(a.rays, slotT, mk3(b.to[0], b.to[1], b.to[2]), mk3(b.td[0], b.td[1], b.td[2]), -FLT_MAX, tag + 1);
                out.child_refr = (int)slotT;
-               list_put(list_count + __popcll(oT & below), slotT);
+               list_put(list_count + __popcll(oT & below), make_uint2(slotT, 0u));
             }
             if (okR) {
                store_qray(a.rays, slotR, mk3(b.ro[0], b.ro[1], b.ro[2]), mk3(b.rd[0], b.rd[1], b.rd[2]), -FLT_MAX, tag + 1);
                out.child_refl = (int)slotR;
-               list_put(list_count + nT + __popcll(oR & below), slotR);
+               list_put(list_count + nT + __popcll(oR & below), make_uint2(slotR, 0u));
             }
-            if (want_sh) list_put(list_count + nT + nR + __popcll(mS & below), RT_SHADOW_ITEM | idx);   /* light 0 of entry idx */
+            if (want_sh) list_put(list_count + nT + nR + __popcll(mS & below), make_uint2(RT_SHADOW_ITEM | idx, 0u));   /* light 0 of entry idx */
             list_count += (int)(nR + nT + cS);
             list_peak = list_count > list_peak ? list_count : list_peak;
             w_refl += cR; w_refr += cT;
@@ -662,7 +698,6 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    /* Every wave reaches its exit in a bounded number of steps: a ray visits each node at most once per
     * stack entry, so RT_STEP_CAP is far beyond any real traversal; hitting it means a corrupted scene and
     * is reported through stats[ST_ABORTED] instead of spinning. */
-   unsigned long long guard = 0;
    for (;;) {
       if (++guard > RT_STEP_CAP) { if (lane == 0) stat_add(stats, ST_ABORTED, 1ULL); break; }
       unsigned long long m_active = __ballot(active);
@@ -693,21 +728,18 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                if (++streams_dry == RT_FETCH_STREAMS) exhausted = true;
             }
          }
-         unsigned item = 0;
-         bool own = !active && rank < take;
-         /* The oldest entries go first (a.take_oldest = 64 lanes' worth): with newest first an old entry waits for
-          * as long as newer ones keep arriving, and the subtree behind it starts only when the queue has run dry
-          * and stretches the end of the launch.  Fewer than 64 mixes the two orders (kept for experiments). */
-         int from_old = take < a.take_oldest ? take : a.take_oldest;
-         if (own) item = rank < from_old ? list_get(rank) : list_get(list_count - 1 - (rank - from_old));
-         list_head = (list_head + from_old) & list_mask;
+         uint2 item = make_uint2(0u, 0u);
+         const bool own = !active && rank < take;
+         /* The oldest entries go first: with newest first an old entry waits for as long as newer ones keep arriving,
+          * and the subtree behind it starts only when the queue has run dry and stretches the end of the launch. */
+         if (own) item = list_get(rank);
+         list_head = (list_head + take) & list_mask;
          list_count -= take;
          bool put_back = false;
          if (!active) {
-            if (OUT == OUT_CHAIN && own && (item & RT_SHADOW_ITEM)) {
+            if (OUT == OUT_CHAIN && own && (item.x & RT_SHADOW_ITEM)) {
                /* the feeler of light k for queue entry `node` (PointLight.h:18-20): from the light to the shaded point */
-               unsigned code = item & ~RT_SHADOW_ITEM;
-               unsigned k = code / a.cap, node = code - k * a.cap;
+               const unsigned node = item.x & ~RT_SHADOW_ITEM, k = item.y;
                unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.points + node);
                unsigned long long p01 = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                unsigned long long p23 = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -715,15 +747,15 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                int hprim = (int)(unsigned)(p23 >> 32);
                const rt_dev_light &Lt = sc.lights[k];
                Ray feeler; feeler.o = mk3(Lt.pos[0], Lt.pos[1], Lt.pos[2]); feeler.d = P - feeler.o;
-               if ((int)k + 1 < sc.n_lights) { item += a.cap; put_back = true; }     /* same entry, next light */
+               if ((int)k + 1 < sc.n_lights) { item.y = k + 1; put_back = true; }     /* same entry, next light */
                c = make_ctx(feeler);
                if (!sc.fast_ok) c.fast = false;
-               tag = (int)code + 1; idx = node;
-               t = FLT_MAX; closest = -1; sp = 0; ray_steps = 0;
+               tag = (int)k; idx = node;
+               t = FLT_MAX; closest = -1; sp = 0; ray_steps = 0; born = (unsigned)guard;
                if (hprim >= sc.n_prims) {
                   /* planes are not in the tree: their own-surface test is done here */
                   float param = plane_intersect(sc, hprim - sc.n_prims, feeler);   /* kernel.cu:351 */
-                  if (param == -1.0f) { a.flags[code] = 0; n_skipped++; }
+                  if (param == -1.0f) n_skipped++;          /* lit, whatever the walk would find: its bit stays clear */
                   else {
                      toBeat = param; mode = MODE_SHADOW; cur = sc.root; active = true;
                      if (cur == RT_ROOT_EMPTY) finish(false);
@@ -734,7 +766,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             } else {
                bool have = false;
                unsigned long long my = 0;
-               if (own) { my = item; have = true; }
+               if (own) { my = item.x; have = true; }
                else if (need > 0) {
                   const unsigned long long q = q_base + (unsigned long long)(rank - take);
                   my = ((q >> 6) * RT_FETCH_STREAMS + my_stream) * 64ULL + (q & 63ULL);
@@ -742,8 +774,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                   if (have && OUT == OUT_CHAIN && a.tile_order) {
                      /* the k-th tile to be started is tile_order[k] of this launch's tiles; where a sample's results
                       * are stored does not change */
-                     unsigned f = (unsigned)my, k = f / a.per_tile;
-                     my = (unsigned long long)a.tile_order[k] * a.per_tile + (f - k * a.per_tile);
+                     unsigned f = (unsigned)my, k = fd_div(f, a.g.per_tile_div);
+                     my = (unsigned long long)a.tile_order[k] * a.g.per_tile + (f - k * a.g.per_tile);
                   }
                }
                if (have) {
@@ -753,7 +785,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                      /* generateCameraRays (kernel.cu:477-498) for sample slot `my`; the ray is also stored, for the
                       * shadow items and the light sums that need it later */
                      int X = 0, Y = 0;
-                     bool inside = slot_to_sample(a.g, (long long)my, X, Y);
+                     bool inside = slot_to_sample(a.g, (unsigned)my, X, Y);
                      Ray pr; pr.o = mk3(0, 0, 0); pr.d = mk3(0, 0, 1);
                      if (inside) pr = camera_ray(a.cam, a.g, X, Y);
                      store_qray(a.rays, my, pr.o, pr.d, -FLT_MAX, inside ? 1 : 0);
@@ -771,7 +803,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                      if (!sc.fast_ok) c.fast = false;
                      toBeat = q.to_beat; idx = (unsigned)my; tag = q.valid; mode = MODE_EXTEND;
                      t = FLT_MAX; closest = -1; sp = 0; cur = sc.root;
-                     active = true; ray_steps = 0;
+                     active = true; ray_steps = 0; born = (unsigned)guard;
                      if (cur == RT_ROOT_EMPTY) finish(false);
                   }
                }
@@ -829,7 +861,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                /* the feeler against its own surface (kernel.cu:351).  A feeler that misses it (-1) can never be
                 * reported shadowed: isFloatLessThan(closest, -1) is false for every accepted t.  The reference
                 * still walks the tree for it; that walk is skipped here and counted separately. */
-               if (dist == -1.0f) { a.flags[tag - 1] = 0; n_skipped++; active = false; cur = RT_CUR_IDLE; }
+               if (dist == -1.0f) { n_skipped++; active = false; cur = RT_CUR_IDLE; }
                else {
                   toBeat = dist; mode = MODE_SHADOW; cur = sc.root;
                   if (cur == RT_ROOT_EMPTY) finish(false);
@@ -1039,7 +1071,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_begin_chunk(unsigned long long *st
 
 /* light: totalLight of every node, the loop of kernel.cu:347-358 with the shadow flags, over every queue entry
  * some wave reserved (entries reserved and not used read as a miss) */
-__global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue, const Hit *hits, const unsigned char *flags,
+__global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue, const Hit *hits, const unsigned *flag_words, unsigned flag_stride,
                                                     const unsigned *n_dev, unsigned cap, int shading, float *totals)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -1051,11 +1083,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue
    if (h.prim >= 0) {
       ShadePoint sp = shade_point(sc, queue, i, h);
       F3 matClr = material_color(sc, sp.m, h.prim, sp.ray, h.t);
+      const unsigned *fw = flag_words + (size_t)i * flag_stride;
+      unsigned bits = 0;
       for (int l = 0; l < sc.n_lights; l++) {
+         if ((l & 31) == 0) bits = fw[l >> 5];
          const rt_dev_light &L = sc.lights[l];
          F3 lc = mk3(L.clr[0], L.clr[1], L.clr[2]);
          F3 lightDir = normalize3(mk3(L.pos[0], L.pos[1], L.pos[2]) - sp.P);    /* PointLight.h:14-16 */
-         bool inShadow = flags[(long long)l * cap + i] != 0;
+         bool inShadow = ((bits >> (l & 31)) & 1u) != 0;
          F3 c = shading == RT_COOK_TORRANCE
                    ? cook_torrance(matClr, sp.m.amb, sp.m.dif, sp.m.spec, sp.m.rough, sp.eye, lightDir, lc, sp.normal, inShadow)
                    : phong(matClr, sp.m.amb, sp.m.dif, sp.m.spec, sp.m.rough, sp.eye, lightDir, lc, sp.normal, inShadow);
@@ -1070,7 +1105,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue
  * with vec3(0) for a ray that was not spawned or hit nothing.  One thread walks one tree (at most
  * 2^RT_MAX_RECURSE - 1 nodes, usually a short chain) with an explicit stack of one frame per level, so every
  * node is evaluated once, by one thread, in the reference's operand order: no atomics, no races. */
-__global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs, const float *totals, long long n_primary, float *rgb,
+__global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs, const float *totals, const unsigned *dur, long long n_primary, float *rgb,
                                                            unsigned *tile_cost, unsigned per_tile)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -1078,7 +1113,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs,
    int node[RT_MAX_RECURSE], stage[RT_MAX_RECURSE];
    float rx[RT_MAX_RECURSE], ry[RT_MAX_RECURSE], rz[RT_MAX_RECURSE];
    int sp = live ? 0 : -1;
-   unsigned deepest = 0;        /* levels below the primary that its bounce tree reaches */
+   unsigned chain_refl[RT_MAX_RECURSE];
+   unsigned chain = 0;          /* the longest chain of dependent rays below (and with) the node just evaluated, in loop turns of its wave */
    node[0] = (int)i; stage[0] = 0;
    F3 ret = mk3(0.0f, 0.0f, 0.0f);
    while (sp >= 0) {
@@ -1087,29 +1123,34 @@ __global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs,
       if (stage[sp] == 0) {
          stage[sp] = 1;
          if (child_refl >= 0 && sp + 1 < RT_MAX_RECURSE) { sp++; node[sp] = child_refl; stage[sp] = 0; continue; }
-         ret = mk3(0.0f, 0.0f, 0.0f);
+         ret = mk3(0.0f, 0.0f, 0.0f); chain = 0;
       }
       if (stage[sp] == 1) {
-         rx[sp] = ret.x; ry[sp] = ret.y; rz[sp] = ret.z;
+         rx[sp] = ret.x; ry[sp] = ret.y; rz[sp] = ret.z; chain_refl[sp] = chain;
          stage[sp] = 2;
          if (child_refr >= 0 && sp + 1 < RT_MAX_RECURSE) { sp++; node[sp] = child_refr; stage[sp] = 0; continue; }
-         ret = mk3(0.0f, 0.0f, 0.0f);
+         ret = mk3(0.0f, 0.0f, 0.0f); chain = 0;
       }
       long long k = node[sp];
       F3 total = mk3(totals[3 * k], totals[3 * k + 1], totals[3 * k + 2]);
       F3 refl = mk3(rx[sp], ry[sp], rz[sp]);
       ret = total * (1.0f - rr.x - rr.y) + rr.x * refl + rr.y * ret;
-      deepest = (unsigned)sp > deepest ? (unsigned)sp : deepest;
+      if (dur) chain = dur[k] + (chain_refl[sp] > chain ? chain_refl[sp] : chain);
       sp--;
    }
    /* rayTrace's clamp (kernel.cu:537-539); NaN passes through clamp unchanged (Util.h:28-30) */
    if (live) { rgb[3 * i] = clamp01(ret.x); rgb[3 * i + 1] = clamp01(ret.y); rgb[3 * i + 2] = clamp01(ret.z); }
    if (tile_cost) {
-      /* How long the dependent chains of this tile's bounce trees are, for the order in which the next frame
-       * starts its tiles.  A wave's 64 primaries lie in one tile (a tile's sample count is a multiple of 64):
-       * the sum of their depths, so that a tile of many deep trees ranks above one with a single deep tree. */
-      for (int o = 32; o > 0; o >>= 1) deepest += __shfl_xor(deepest, o);
-      if ((threadIdx.x & 63) == 0 && live && deepest) atomicAdd(&tile_cost[(unsigned)(i / per_tile)], deepest);
+      /* What this tile costs, for the order in which the next frame starts its tiles: how long its longest chain of
+       * dependent rays was in flight.  A tile started late must be one whose chains are short, or the launch ends on a
+       * few waves finishing them.  A wave's 64 primaries lie in one tile (a tile's sample count is a multiple of 64). */
+      unsigned cost = live ? chain : 0u;
+      unsigned sum = cost;
+      for (int o = 32; o > 0; o >>= 1) { unsigned other = __shfl_xor(cost, o); cost = other > cost ? other : cost; sum += __shfl_xor(sum, o); }
+      if ((threadIdx.x & 63) == 0 && live && cost) {
+         atomicMax(&tile_cost[2 * (unsigned)(i / per_tile)], cost);
+         atomicAdd(&tile_cost[2 * (unsigned)(i / per_tile) + 1], sum);
+      }
    }
 }
 
@@ -1219,7 +1260,7 @@ struct rt_scene {
    unsigned long long *d_stats;
    unsigned long long *h_stats;  /* pinned */
    float node_factor;       /* queue entries per primary ray the chain kernel gets room for; grows when a frame overflows */
-   unsigned *d_lists;       /* the waves' lists of spawned rays (k_trace): list_waves rings of list_cap entries */
+   uint2 *d_lists;          /* the waves' lists of spawned rays (k_trace): list_waves rings of list_cap entries */
    unsigned list_cap, list_waves;
    /* Tiles are started costliest first, by the previous frame's depth of the bounce trees per tile: the waves that
     * pick up the last primaries of a launch then hold short chains, and the launch does not end on a few long ones. */
@@ -1236,7 +1277,8 @@ struct rt_scene {
    std::vector<int32_t> prim_ids_host;      /* host copy of DScene::prim_ids */
    /* launch shape and tuning of the traversal kernel, read once per scene from its device and the environment */
    int trace_blocks;        /* workgroups of a full traversal launch: what the device holds at 4 waves per SIMD */
-   int refill_idle, node_burst, take_oldest, use_tile_order;
+   int refill_idle, node_burst, use_tile_order, order_classes;
+   double order_mean_weight;
    unsigned reserve;        /* queue entries a wave reserves at a time for its bounce rays */
 };
 
@@ -1568,8 +1610,9 @@ static void scene_tuning(rt_scene *s)
    s->trace_blocks = env_int("RT_TRACE_BLOCKS", cus * 4);
    s->refill_idle = env_int("RT_REFILL_IDLE", RT_REFILL_IDLE);
    s->node_burst = env_int("RT_NODE_BURST", RT_NODE_BURST);
-   s->take_oldest = env_int("RT_TAKE_OLDEST", RT_TAKE_OLDEST, true);
    s->use_tile_order = env_int("RT_TILE_ORDER", 1, true);
+   s->order_classes = env_int("RT_ORDER_CLASSES", RT_ORDER_CLASSES);
+   s->order_mean_weight = (double)env_int("RT_ORDER_MEAN_WEIGHT", RT_ORDER_MEAN_WEIGHT, true);
    int r = env_int("RT_RESERVE", RT_RESERVE);
    s->reserve = (unsigned)(r < 128 ? 128 : r);      /* one spawn stage can ask for 128 entries */
 }
@@ -1580,7 +1623,7 @@ static int ensure_lists(rt_scene *s)
    const unsigned waves = (unsigned)s->trace_blocks * (RT_BLOCK / 64);
    if (s->d_lists && s->list_waves == waves) return RT_OK;
    if (s->d_lists) { (void)hipFree(s->d_lists); s->d_lists = nullptr; }
-   hipError_t e = hipMalloc((void **)&s->d_lists, sizeof(unsigned) * (size_t)waves * s->list_cap);
+   hipError_t e = hipMalloc((void **)&s->d_lists, sizeof(uint2) * (size_t)waves * s->list_cap);
    if (e != hipSuccess) { rt_set_error("hipMalloc of the spawn lists (%u x %u entries) failed: %s", waves, s->list_cap, hipGetErrorString(e)); return RT_ERR_HIP; }
    s->list_waves = waves;
    return RT_OK;
@@ -1592,7 +1635,7 @@ static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs 
    unsigned long long want = (n_hint + RT_BLOCK - 1) / RT_BLOCK;
    unsigned blocks = (unsigned)(want < (unsigned long long)s->trace_blocks ? want : (unsigned long long)s->trace_blocks);
    if (blocks == 0) return;
-   a.refill_idle = s->refill_idle; a.node_burst = s->node_burst; a.take_oldest = s->take_oldest;
+   a.refill_idle = s->refill_idle; a.node_burst = s->node_burst;
    a.reserve = s->reserve;
    a.stats = s->d_stats;
 #define RT_LAUNCH_TRACE(O, C) hipLaunchKernelGGL((k_trace<O, C>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, a)
@@ -1651,6 +1694,10 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    g.tiles_x = (p->width + RT_TILE - 1) / RT_TILE;
    g.tile_first = tile_first; g.tile_stride = tile_stride; g.k0 = 0;
    g.ts = RT_TILE * sroot; g.patches_per_row = g.ts / 8;
+   g.per_tile = (unsigned)(g.ts * g.ts);
+   g.per_tile_div = make_fastdiv(g.per_tile); g.patches_per_row_div = make_fastdiv((unsigned)g.patches_per_row);
+   g.tiles_x_div = make_fastdiv((unsigned)g.tiles_x);
+   g.inv_res_w = 1.0f / (float)g.res_w; g.inv_res_h = 1.0f / (float)g.res_h;
    g.jitter = p->jitter; g.seed = p->seed;
    DCamera cam = make_camera(s->camera);
    const DScene &sc = s->d;
@@ -1665,13 +1712,9 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    for (int attempt = 0;; attempt++) {
       memset(&st, 0, sizeof st);
       attempts = attempt + 1;
-      /* chunk size: a chunk is bounded by its queue entries (2^24 primaries) and by its shadow feelers (one flag
-       * byte per light per queue entry; their number must stay below 2^31 for the shadow items' numbering: up to
-       * two gigabytes of flags); a frame is one chunk whenever that allows */
+      /* chunk size: a chunk is bounded by its queue entries; a frame is one chunk whenever that allows */
       double F = max_rec > 1 ? (double)s->node_factor : 1.0;
       long long slots_cap = max_batch_slots();
-      const double flag_cap = (double)((1LL << 31) - (1LL << 26));
-      if (L > 0 && ((double)slots_cap * F + 64.0) * L > flag_cap) slots_cap = (long long)((flag_cap / L - 64.0) / F);
       long long tiles_cap = slots_cap / per_tile; if (tiles_cap < 1) tiles_cap = 1;
       long long tiles_min = (128 * 1024) / per_tile; if (tiles_min < 1) tiles_min = 1;
       long long chunk_tiles = n_sel;
@@ -1687,7 +1730,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       const long long launch_waves = (np_max + RT_BLOCK - 1) / RT_BLOCK < s->trace_blocks ? (np_max + RT_BLOCK - 1) / RT_BLOCK * (RT_BLOCK / 64)
                                                                                            : (long long)s->trace_blocks * (RT_BLOCK / 64);
       long long cap_ll = (long long)((double)np_max * F) + (max_rec > 1 ? launch_waves * (long long)s->reserve : 0) + 64;
-      if (cap_ll > 0x7fffffffLL / (L > 0 ? L : 1)) { rt_set_error("ray queue too large"); return RT_ERR_TOO_LARGE; }
+      if (cap_ll >= 0x7fffffffLL) { rt_set_error("ray queue too large"); return RT_ERR_TOO_LARGE; }       /* entry numbers keep their top bit free */
       const unsigned cap = (unsigned)cap_ll;
       size_t used = 0;
       auto carve = [&](size_t bytes) { size_t o = used; used += align_up(bytes ? bytes : 1, 256); return o; };
@@ -1695,8 +1738,11 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       const size_t o_recs = carve(sizeof(SpawnRec) * (size_t)cap), o_totals = carve(sizeof(float) * 3 * (size_t)cap);
       const size_t o_points = carve(sizeof(float4) * (size_t)cap);
       const size_t o_rgb = carve(sizeof(float) * 3 * (size_t)np_max);
-      const size_t n_feelers = (size_t)(L > 0 ? L : 0) * (size_t)cap;
-      const size_t o_flags = carve(n_feelers);
+      const size_t o_dur = carve(sizeof(unsigned) * (size_t)cap);
+      /* one bit per (queue entry, light): isInShadow, set by the feelers that found an occluder */
+      const unsigned flag_stride = (unsigned)((L > 0 ? L : 1) + 31) / 32u;
+      const size_t flag_bytes = sizeof(unsigned) * (size_t)flag_stride * (size_t)cap;
+      const size_t o_flags = carve(flag_bytes);
       const size_t slice = used;
       if (slice * (size_t)ring > s->arena.cap) { int rc = arena_reserve(s->arena, slice * (size_t)ring); if (rc != RT_OK) return rc; }
       { int rc = ensure_lists(s); if (rc != RT_OK) return rc; }
@@ -1704,7 +1750,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
 
       /* tile start order: only for a frame that is one launch, and from a frame of the same geometry */
       const long long key[6] = {p->width, p->height, p->sample_count, tile_first, tile_stride, n_sel};
-      const bool track_cost = s->use_tile_order && n_chunks == 1 && view != VIEW_PRIMARY && max_rec > 1 && per_tile % 64 == 0;
+      const bool track_cost = s->use_tile_order && n_chunks == 1 && view != VIEW_PRIMARY && per_tile % 64 == 0;
       if (track_cost && n_sel > s->order_cap) {
          if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
          if (s->d_tile_order) (void)hipFree(s->d_tile_order);
@@ -1712,8 +1758,9 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          if (s->h_tile_order) (void)hipHostFree(s->h_tile_order);
          s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false; s->order_dirty = true;
          const size_t bytes = sizeof(unsigned) * (size_t)n_sel;
-         HIP_TRY(hipMalloc((void **)&s->d_tile_cost, bytes)); HIP_TRY(hipMalloc((void **)&s->d_tile_order, bytes));
-         HIP_TRY(hipHostMalloc((void **)&s->h_tile_cost, bytes, hipHostMallocDefault));
+         /* two cost words per tile: its longest chain and the sum of its chains */
+         HIP_TRY(hipMalloc((void **)&s->d_tile_cost, 2 * bytes)); HIP_TRY(hipMalloc((void **)&s->d_tile_order, bytes));
+         HIP_TRY(hipHostMalloc((void **)&s->h_tile_cost, 2 * bytes, hipHostMallocDefault));
          HIP_TRY(hipHostMalloc((void **)&s->h_tile_order, bytes, hipHostMallocDefault));
          s->order_cap = n_sel;
       }
@@ -1739,16 +1786,16 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
 
          {
             /* counters to zero, spawned rays appended behind the primaries, tile costs and (first chunk) statistics cleared */
-            const int n_stats = c == 0 ? ST_COUNT * RT_STAT_REPL : 0, n_cost = track_cost ? (int)n_sel : 0;
+            const int n_stats = c == 0 ? ST_COUNT * RT_STAT_REPL : 0, n_cost = track_cost ? 2 * (int)n_sel : 0;
             const int n_init = n_stats > n_cost ? (n_stats > RT_CTR_WORDS ? n_stats : RT_CTR_WORDS) : (n_cost > RT_CTR_WORDS ? n_cost : RT_CTR_WORDS);
             hipLaunchKernelGGL(k_begin_chunk, dim3(grid_for(n_init)), dim3(RT_BLOCK), 0, S, c == 0 ? s->d_stats : (unsigned long long *)nullptr,
                                n_stats, s->d_ctr, ctr.tail, (unsigned)np, track_cost ? s->d_tile_cost : (unsigned *)nullptr, n_cost);
             TraceArgs a; memset(&a, 0, sizeof a);
             a.rays = queue; a.n = (unsigned long long)np; a.hits = hits; a.next = ctr.next_chain;
-            a.flags = AT(unsigned char, r, o_flags);
+            a.flag_words = AT(unsigned, r, o_flags); a.flag_stride = flag_stride;
+            if (L > 0) HIP_TRY(hipMemsetAsync(a.flag_words, 0, flag_bytes, S));
             a.recs = recs; a.tail = ctr.tail; a.cap = cap; a.max_rec = max_rec; a.cam = cam; a.g = g;
             a.points = AT(float4, r, o_points);
-            a.per_tile = (unsigned)per_tile;
             a.lists = s->d_lists; a.list_cap = s->list_cap;
             if (!a.lists || a.list_cap == 0 || (a.list_cap & (a.list_cap - 1)) != 0) { rt_set_error("internal: spawn lists not set up"); return RT_ERR_HIP; }
             if (have_order) {
@@ -1758,6 +1805,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
                }
                a.tile_order = s->d_tile_order;
             }
+            if (track_cost) a.dur = AT(unsigned, r, o_dur);
             Timer &tm = ev.begin(S, &st.ms_trace);
             launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, S);
             ev.end(tm, S); st.launches_trace++;
@@ -1769,15 +1817,15 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          {
             Timer &tm = ev.begin(S, &st.ms_light);
             hipLaunchKernelGGL(k_light, dim3(grid_for(cap)), dim3(RT_BLOCK), 0, S, sc, (const QRay *)queue, (const Hit *)hits,
-                               (const unsigned char *)AT(unsigned char, r, o_flags), (const unsigned *)ctr.tail, cap,
+                               (const unsigned *)AT(unsigned, r, o_flags), flag_stride, (const unsigned *)ctr.tail, cap,
                                p->shading, AT(float, r, o_totals));
             ev.end(tm, S);
             Timer &tc = ev.begin(S, &st.ms_combine);
             hipLaunchKernelGGL(k_combine_tree, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, (const SpawnRec *)recs,
-                               (const float *)AT(float, r, o_totals), np, AT(float, r, o_rgb),
+                               (const float *)AT(float, r, o_totals), track_cost ? (const unsigned *)AT(unsigned, r, o_dur) : (const unsigned *)nullptr, np, AT(float, r, o_rgb),
                                track_cost ? s->d_tile_cost : (unsigned *)nullptr, (unsigned)per_tile);
             ev.end(tc, S);
-            if (track_cost) HIP_TRY(hipMemcpyAsync(s->h_tile_cost, s->d_tile_cost, sizeof(unsigned) * (size_t)n_sel, hipMemcpyDeviceToHost, S));
+            if (track_cost) HIP_TRY(hipMemcpyAsync(s->h_tile_cost, s->d_tile_cost, 2 * sizeof(unsigned) * (size_t)n_sel, hipMemcpyDeviceToHost, S));
          }
          if (view == VIEW_FRAME) {
             Timer &tr = ev.begin(S, &st.ms_resolve);
@@ -1817,14 +1865,25 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       }
       if (max_rec > 1 && wanted * 1.1 > F) s->node_factor = (float)(wanted * 1.25 < 64.0 ? wanted * 1.25 : 64.0);
       if (track_cost) {
-         /* costliest first, in 17 classes (none, 1, 2-3, 4-7, ...); tiles of a class stay in image order, so
-          * neighbouring waves still work on neighbouring tiles */
-         long long start[18] = {0};
-         auto cls = [](unsigned c) { int b = 0; while (c) { b++; c >>= 1; } return b > 16 ? 16 : b; };
-         for (long long k = 0; k < n_sel; k++) start[16 - cls(s->h_tile_cost[k]) + 1]++;
-         for (int b = 0; b < 17; b++) start[b + 1] += start[b];
+         /* Costliest first, in a few classes of equal size (by rank of the tile's longest chain); tiles of a class stay
+          * in image order, so neighbouring waves still work on neighbouring tiles: a scattered order costs more in the
+          * caches than the shorter tail wins. */
+         const int classes = s->order_classes;
+         /* a tile's cost: its longest chain, plus order_mean_weight times its mean chain (a tile full of long chains
+          * keeps its waves busy longer than one with a single long chain) */
+         std::vector<unsigned> costs((size_t)n_sel);
+         for (long long k = 0; k < n_sel; k++)
+            costs[(size_t)k] = s->h_tile_cost[2 * k] + (unsigned)((double)s->h_tile_cost[2 * k + 1] * s->order_mean_weight / (double)per_tile);
+         std::vector<unsigned> sorted(costs);
+         std::sort(sorted.begin(), sorted.end(), std::greater<unsigned>());
+         std::vector<unsigned> bound((size_t)classes);        /* class c holds costs above bound[c] (and not in an earlier class) */
+         for (int c = 0; c < classes; c++) { long long at = (long long)(c + 1) * n_sel / classes; bound[(size_t)c] = at < n_sel ? sorted[(size_t)at] : 0u; }
+         auto cls = [&](unsigned cost) { int c = 0; while (c + 1 < classes && cost <= bound[(size_t)c]) c++; return c; };
+         std::vector<long long> start((size_t)classes + 1, 0);
+         for (long long k = 0; k < n_sel; k++) start[(size_t)cls(costs[(size_t)k]) + 1]++;
+         for (int c = 0; c < classes; c++) start[(size_t)c + 1] += start[(size_t)c];
          std::vector<int> order((size_t)n_sel);
-         for (long long k = 0; k < n_sel; k++) order[(size_t)start[16 - cls(s->h_tile_cost[k])]++] = (int)k;
+         for (long long k = 0; k < n_sel; k++) order[(size_t)start[(size_t)cls(costs[(size_t)k])]++] = (int)k;
          const bool same = s->order_valid && memcmp(key, s->order_key, sizeof key) == 0 &&
                            memcmp(order.data(), s->h_tile_order, sizeof(int) * (size_t)n_sel) == 0;
          if (!same) {         /* an unchanged order (a still camera) is not uploaded again */

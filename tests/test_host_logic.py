@@ -40,12 +40,33 @@ def test_library_exports_every_declared_symbol():
         assert getattr(lib, name) is not None
 
 
-def test_struct_sizes_match_header():
-    assert C.sizeof(abi.Camera) == 48
-    assert C.sizeof(abi.RenderParams) == 40
-    assert C.sizeof(abi.SceneInfo) == 56
-    # rt_stats: 8 u64, 7 floats + 2 i32 (36 bytes -> padded to 40), 10 u64
-    assert C.sizeof(abi.Stats) == 8 * 8 + 40 + 10 * 8
+def test_struct_sizes_match_header(tmp_path):
+    """The ctypes mirrors against the C compiler's view of include/raytracer_amd.h: sizes of every struct that crosses
+    the ABI, and the offset of every rt_stats field."""
+    import subprocess
+    fields = [n for n, _ in abi.Stats._fields_ if not n.startswith("pad")]
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "raytracer_amd.h"', 'int main(void) {']
+    for name in ("rt_camera", "rt_render_params", "rt_scene_info", "rt_stats", "rt_material", "rt_modifier", "rt_sphere", "rt_triangle",
+                 "rt_box", "rt_smooth_triangle", "rt_plane", "rt_light", "rt_texture", "rt_scene_desc", "rt_bvh_node"):
+        prog.append(f'printf("{name} %zu\\n", sizeof({name}));')
+    for f in fields:
+        prog.append(f'printf("rt_stats.{f} %zu\\n", offsetof(rt_stats, {f}));')
+    prog += ['return 0; }']
+    src = tmp_path / "sizes.c"
+    src.write_text("\n".join(prog))
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    mirror = {"rt_camera": abi.Camera, "rt_render_params": abi.RenderParams, "rt_scene_info": abi.SceneInfo, "rt_stats": abi.Stats,
+              "rt_texture": abi.Texture, "rt_scene_desc": abi.SceneDesc}
+    for name, cls in mirror.items():
+        assert C.sizeof(cls) == int(got[name]), name
+    for name, dt in (("rt_material", abi.material_dtype), ("rt_modifier", abi.modifier_dtype), ("rt_sphere", abi.sphere_dtype),
+                     ("rt_triangle", abi.triangle_dtype), ("rt_box", abi.box_dtype), ("rt_smooth_triangle", abi.smooth_triangle_dtype),
+                     ("rt_plane", abi.plane_dtype), ("rt_light", abi.light_dtype), ("rt_bvh_node", abi.bvh_node_dtype)):
+        assert dt.itemsize == int(got[name]), name
+    for f in fields:
+        assert getattr(abi.Stats, f).offset == int(got[f"rt_stats.{f}"]), f
 
 
 def test_missing_library_fails_loudly(tmp_path):
