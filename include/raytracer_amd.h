@@ -281,6 +281,16 @@ int rt_trace_primary(const rt_scene *scene, const rt_render_params *params,
 int rt_trace_rays(const rt_scene *scene, int64_t n, const float *rays_host,
                   const float *to_beat_host, int32_t *prim_ids_host, float *t_host);
 
+/* rt_trace_rays for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as rt_trace_rays, but
+ * the call makes no hipMalloc / hipFree: its working memory (counters, the staged rays, the queue entries, the hits)
+ * is an array inside the library, RT_TRACE_RAYS_STATIC_MAX rays' worth (36 MB), which every device the library runs
+ * on holds until the process ends.  More rays than that are rejected with RT_ERR_TOO_LARGE.  All calls on one device
+ * share that array: calls that overlap on one device race (calls on different devices do not). */
+#define RT_TRACE_RAYS_STATIC_MAX 524288
+int rt_trace_rays_static(const rt_scene *scene, int64_t n, const float *rays_host,
+                         const float *to_beat_host, int32_t *prim_ids_host, float *t_host);
+
 /* Per-sample clamped float RGB, the reference's antiAliasBuffer
  * (kernel.cu:537-541): n_samples x 3 floats, host. */
 int rt_render_samples(const rt_scene *scene, const rt_render_params *params,

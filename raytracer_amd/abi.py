@@ -29,6 +29,7 @@ RT_JITTER_NONE, RT_JITTER_HASH = 0, 1
 RT_OUT_FRAME, RT_OUT_TILES = 0, 1
 RT_TILE = 32
 RT_MAX_RECURSE = 6
+RT_TRACE_RAYS_STATIC_MAX = 524288
 RT_SCENE_DEFAULT, RT_SCENE_COUNTERS, RT_SCENE_FAST_BVH, RT_SCENE_GPU_BVH = 0, 1, 2, 4
 
 f32, i32 = np.float32, np.int32
@@ -111,7 +112,7 @@ class SceneInfo(C.Structure):
 EXPORTED_SYMBOLS = [
     "rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_create_host", "rt_scene_destroy", "rt_scene_get_info",
     "rt_scene_get_bvh", "rt_scene_set_camera", "rt_render", "rt_render_device", "rt_tile_count",
-    "rt_untile_device", "rt_trace_primary", "rt_trace_rays", "rt_render_samples",
+    "rt_untile_device", "rt_trace_primary", "rt_trace_rays", "rt_trace_rays_static", "rt_render_samples",
     "rt_parse_pov", "rt_scene_desc_free", "rt_load_bmp", "rt_write_tga", "launch_kernel",
 ]
 
@@ -145,6 +146,7 @@ def load_library(path=None):
     lib.rt_untile_device.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.rt_trace_primary.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
     lib.rt_trace_rays.argtypes = [vp, i64c, vp, vp, vp, vp]
+    lib.rt_trace_rays_static.argtypes = [vp, i64c, vp, vp, vp, vp]
     lib.rt_render_samples.argtypes = [vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]
     lib.rt_parse_pov.argtypes = [C.c_char_p, C.POINTER(C.POINTER(SceneDesc))]
     lib.rt_scene_desc_free.argtypes = [C.POINTER(SceneDesc)]

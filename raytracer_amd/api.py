@@ -158,14 +158,16 @@ class Scene:
         _check(self._lib, self._lib.rt_trace_primary(self._h, C.byref(p), prim.ctypes.data, t.ctypes.data))
         return prim, t
 
-    def trace_rays(self, rays, to_beat=None):
+    def trace_rays(self, rays, to_beat=None, static=False):
+        """Closest hits of arbitrary rays (n x {o, d}); `static` goes through rt_trace_rays_static, the variant
+        that allocates no device memory (at most abi.RT_TRACE_RAYS_STATIC_MAX rays)."""
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
         n = rays.shape[0]
         prim = np.empty(n, np.int32)
         t = np.empty(n, np.float32)
         tb = None if to_beat is None else np.ascontiguousarray(to_beat, dtype=np.float32)
-        _check(self._lib, self._lib.rt_trace_rays(self._h, n, rays.ctypes.data, tb.ctypes.data if tb is not None else None,
-                                                  prim.ctypes.data, t.ctypes.data))
+        fn = self._lib.rt_trace_rays_static if static else self._lib.rt_trace_rays
+        _check(self._lib, fn(self._h, n, rays.ctypes.data, tb.ctypes.data if tb is not None else None, prim.ctypes.data, t.ctypes.data))
         return prim, t
 
     def render_samples(self, width, height, sample_count=1, shading=PHONG, jitter=abi.RT_JITTER_NONE, seed=0,
