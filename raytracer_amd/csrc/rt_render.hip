@@ -377,6 +377,7 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2 };
 #define RT_CTR_WORDS (8 * ((int)RT_FETCH_STREAMS + 1))   /* 64-bit words of a launch's counters: the streams' (64 bytes apart), then the queue tail */
 #define RT_ORDER_CLASSES 64 /* classes of tile cost that decide the order in which a frame's tiles are started */
 #define RT_ORDER_MEAN_WEIGHT 4
+#define RT_LDS_STACK 14     /* stack entries per lane kept in LDS; deeper trees spill the rest to global memory */
 #define RT_RESERVE 256      /* queue entries a wave reserves at a time for the bounce rays it spawns */
 
 struct TraceArgs {
@@ -400,6 +401,7 @@ struct TraceArgs {
    uint2 *lists;                /* one ring of list_cap (a power of two) entries per wave of the launch: {queue entry | RT_SHADOW_ITEM, light} */
    unsigned list_cap;
    const int *tile_order;       /* when non-null: the order in which the launch's tiles are started (costliest first) */
+   StackEntry *spill;           /* SPILL kernels: stack entries beyond the RT_LDS_STACK kept in LDS, [entry - RT_LDS_STACK][lane of the launch] */
    unsigned *dur;               /* when non-null: per queue entry, how many turns of its wave's loop the closest-hit ray was in flight */
 };
 
@@ -485,11 +487,24 @@ __device__ __forceinline__ BounceRays bounce_rays(const rt_dev_prim *prims, cons
    return b;
 }
 
-template <int OUT, bool COUNT>
+template <int OUT, bool COUNT, bool SPILL>
 __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_trace(DScene sc, TraceArgs a)
 {
+   /* The per-lane stack of deferred siblings: one column per lane in LDS.  A tree deeper than RT_LDS_STACK levels
+    * (SPILL) keeps the entries beyond that in global memory, a column per lane of the launch, so that deep trees do
+    * not cost the four workgroups per CU their LDS; a ray rarely defers that many siblings at once. */
    StackEntry *stack = lds_stack + threadIdx.x;
    const int stride = RT_BLOCK;
+   StackEntry *const spill = SPILL ? a.spill + ((size_t)blockIdx.x * RT_BLOCK + threadIdx.x) : nullptr;
+   const size_t spill_stride = SPILL ? (size_t)gridDim.x * RT_BLOCK : 0;
+   auto stack_get = [&](int i) {
+      if (SPILL && i >= RT_LDS_STACK) return spill[(size_t)(i - RT_LDS_STACK) * spill_stride];
+      return stack[i * stride];
+   };
+   auto stack_put = [&](int i, StackEntry e) {
+      if (SPILL && i >= RT_LDS_STACK) spill[(size_t)(i - RT_LDS_STACK) * spill_stride] = e;
+      else stack[i * stride] = e;
+   };
    const unsigned lane = __lane_id();
    const unsigned long long below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
    /* OUT_CHAIN: this wave's list of spawned rays and shadow items still to be started, a ring of a.list_cap entries in
@@ -562,7 +577,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
     * pushes or pops, never both, so the top of the stack at the start of a step is the entry its pop starts with,
     * and the LDS round trip overlaps the node or primitive fetch instead of following it. */
    auto peek = [&]() {
-      StackEntry e = stack[(sp > 0 ? sp - 1 : 0) * stride];
+      StackEntry e = stack_get(sp > 0 ? sp - 1 : 0);
       asm volatile("" : "+v"(e.child), "+v"(e.dist));      /* one 64-bit read, issued here */
       return e;
    };
@@ -579,7 +594,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       if (!found) {
          while (sp > 0) {
             sp--;
-            StackEntry e = stack[sp * stride];
+            StackEntry e = stack_get(sp);
             if (e.dist < t) { cur = e.child; found = true; break; }
          }
          if (!found) finish(false);
@@ -618,7 +633,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       float other = goR ? l : r;
       if ((goR || goL) && other < inf) {
          StackEntry e; e.child = goR ? ch.x : ch.y; e.dist = other;
-         stack[sp * stride] = e; sp++;
+         stack_put(sp, e); sp++;
       }
       if (goR || goL) cur = goR ? ch.y : ch.x;
       else pop(top);
@@ -1261,6 +1276,7 @@ struct rt_scene {
    unsigned long long *d_stats;
    unsigned long long *h_stats;  /* pinned */
    float node_factor;       /* queue entries per primary ray the chain kernel gets room for; grows when a frame overflows */
+   StackEntry *d_spill;     /* trees deeper than RT_LDS_STACK: the stack entries beyond LDS, (depth - RT_LDS_STACK) x lanes of a full launch */
    uint2 *d_lists;          /* the waves' lists of spawned rays (k_trace): list_waves rings of list_cap entries */
    unsigned list_cap, list_waves;
    /* Tiles are started costliest first, by the previous frame's depth of the bounce trees per tile: the waves that
@@ -1320,6 +1336,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
    if (s->d_stats) (void)hipFree(s->d_stats);
    if (s->h_stats) (void)hipHostFree(s->h_stats);
    if (s->d_lists) (void)hipFree(s->d_lists);
+   if (s->d_spill) (void)hipFree(s->d_spill);
    if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
    if (s->d_tile_order) (void)hipFree(s->d_tile_order);
    if (s->h_tile_cost) (void)hipHostFree(s->h_tile_cost);
@@ -1347,7 +1364,7 @@ extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
    s->device = -1; s->flags = 0; s->streams_ok = false; s->ms_build_device = 0.0f;
    s->dev_blob = nullptr; s->dev_bytes = 0; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
    s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false; s->order_dirty = true;
-   s->d_lists = nullptr; s->list_cap = first_list_cap(); s->list_waves = 0;
+   s->d_lists = nullptr; s->list_cap = first_list_cap(); s->list_waves = 0; s->d_spill = nullptr;
    s->camera = desc->camera; s->has_camera = desc->has_camera; s->ms_upload = 0;
    auto t0 = std::chrono::steady_clock::now();
    int st = rt_flatten_scene(desc, &s->host);
@@ -1372,7 +1389,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->device = device; s->flags = flags; s->streams_ok = false; s->ms_build_device = 0.0f;
    s->dev_blob = nullptr; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
    s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false; s->order_dirty = true;
-   s->d_lists = nullptr; s->list_cap = first_list_cap(); s->list_waves = 0;
+   s->d_lists = nullptr; s->list_cap = first_list_cap(); s->list_waves = 0; s->d_spill = nullptr;
    s->camera = desc->camera; s->has_camera = desc->has_camera;
    scene_tuning(s);
    { char *unused = nullptr; (void)scratch_address(device, &unused); }   /* this device's static working memory (rt_trace_rays_static), looked up while the device is current; a failure is reported by that call */
@@ -1451,6 +1468,10 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
        hipMalloc((void **)&s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long)) != hipSuccess ||
        hipHostMalloc((void **)&s->h_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
       rt_set_error("allocation of queue counters failed"); rt_scene_destroy(s); return RT_ERR_HIP;
+   }
+   if (h.tree_depth > RT_LDS_STACK) {
+      const size_t bytes = sizeof(StackEntry) * (size_t)(h.tree_depth - RT_LDS_STACK) * (size_t)s->trace_blocks * RT_BLOCK;
+      if (hipMalloc((void **)&s->d_spill, bytes) != hipSuccess) { rt_set_error("allocation of %zu bytes of traversal stack failed", bytes); rt_scene_destroy(s); return RT_ERR_HIP; }
    }
    {
       bool ok = hipStreamCreateWithFlags(&s->chain, hipStreamNonBlocking) == hipSuccess;
@@ -1575,25 +1596,17 @@ static long long max_batch_slots()
 {
    const char *e = getenv("RT_MAX_BATCH_SLOTS");
    long long v = e ? atoll(e) : 0;
-   return v > 0 ? v : (long long)(1 << 24);
+   return v > 0 ? v : (long long)(1 << 26);
 }
 
 static int trace_lds_bytes(const rt_scene *s, size_t *out)
 {
-   /* the stack holds at most one deferred sibling per internal level */
+   /* the stack holds at most one deferred sibling per internal level; RT_LDS_STACK of them live in LDS */
    int depth = s->host.tree_depth > 0 ? s->host.tree_depth : 1;
-   size_t lds_bytes = sizeof(StackEntry) * (size_t)RT_BLOCK * (size_t)depth;
-   if (lds_bytes > 160 * 1024) { rt_set_error("BVH depth %d needs %zu bytes of LDS", s->host.tree_depth, lds_bytes); return RT_ERR_TOO_LARGE; }
-   if (lds_bytes > 64 * 1024) {
-      HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_HIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_HIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_CHAIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipFuncSetAttribute((const void *)k_trace<OUT_CHAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-   }
-   *out = lds_bytes;
+   if (depth > RT_LDS_STACK) depth = RT_LDS_STACK;
+   *out = sizeof(StackEntry) * (size_t)RT_BLOCK * (size_t)depth;
    return RT_OK;
 }
-
 
 static int env_int(const char *name, int fallback, bool allow_zero = false)
 {
@@ -1641,7 +1654,10 @@ static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs 
    a.refill_idle = s->refill_idle; a.node_burst = s->node_burst;
    a.reserve = s->reserve;
    if (!a.stats) a.stats = s->d_stats;
-#define RT_LAUNCH_TRACE(O, C) hipLaunchKernelGGL((k_trace<O, C>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, a)
+   a.spill = s->d_spill;
+   const bool spill = s->host.tree_depth > RT_LDS_STACK;
+#define RT_LAUNCH_TRACE(O, C) do { if (spill) hipLaunchKernelGGL((k_trace<O, C, true>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, a); \
+                                   else hipLaunchKernelGGL((k_trace<O, C, false>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, a); } while (0)
    if (out_mode == OUT_CHAIN) { if (count) RT_LAUNCH_TRACE(OUT_CHAIN, true); else RT_LAUNCH_TRACE(OUT_CHAIN, false); }
    else { if (count) RT_LAUNCH_TRACE(OUT_HIT, true); else RT_LAUNCH_TRACE(OUT_HIT, false); }
 #undef RT_LAUNCH_TRACE
