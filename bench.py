@@ -55,7 +55,7 @@ SIMDS = 256 * 4
 VALU_ISSUE_PER_SIMD = 1.2e9    # one wave64 f32 instruction per 2 cycles at 2.4 GHz
 FP32_PEAK_TFLOPS = 78.6        # non-packed f32 FMA peak (half the 157.3 TFLOP/s packed figure)
 WEAK_FRAMES = {1: (1920, 1080), 2: (3840, 1080), 4: (3840, 2160), 8: (7680, 2160)}
-DOMINANT = "k_trace<2, false>"
+DOMINANT = "k_trace<2, false"        # the uncounted whole-forest traversal kernel, as rocprofv3 names it (prefix)
 PROFILE_TAG = "r02"
 README_WALL_S = {"dragon_large_tris": 1.230, "balls2": 1.875}    # the reference's README:30-40, whole program, unnamed sm_20 GPU
 
@@ -109,9 +109,12 @@ def profile_counter(pas, counter):
     """Per-launch value of a counter of the dominant kernel from the committed counter passes of this command."""
     path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_summary.json")
     try:
-        return json.load(open(path))[pas][DOMINANT][counter]["per_launch"]
+        for kernel, counters in json.load(open(path))[pas].items():
+            if kernel.startswith(DOMINANT):
+                return counters[counter]["per_launch"]
     except Exception:
-        return None
+        pass
+    return None
 
 
 def best_of(scene, params, out_ptr, stream, frames):

@@ -303,8 +303,9 @@ int rt_render_samples(const rt_scene *scene, const rt_render_params *params,
 int rt_parse_pov(const char *path, rt_scene_desc **out);
 void rt_scene_desc_free(rt_scene_desc *desc);
 
-/* readBMP (kernel.cu:35-61): a 24-bit uncompressed .bmp into tex->width/height/rgba (malloc'ed; a description
- * from rt_parse_pov frees it in rt_scene_desc_free, any other owner frees it with free()). */
+/* readBMP (kernel.cu:35-61): a 24-bit uncompressed .bmp into tex->width/height/rgba.  rgba is malloc'ed and
+ * overwrites the field without looking at its old value (so *tex need not be initialised, and a buffer it pointed to
+ * stays the caller's); a description from rt_parse_pov frees it in rt_scene_desc_free, any other owner with free(). */
 int rt_load_bmp(const char *path, rt_texture *tex);
 
 /* 24-bit uncompressed TGA exactly as the reference's driver + Image::WriteTga

@@ -18,7 +18,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = "k_trace<2, false>"
+DOMINANT = "k_trace<2, false"        # the uncounted whole-forest traversal kernel (with or without the stack-spill variant)
 
 
 def short(name):
@@ -55,10 +55,10 @@ def main():
     json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     fetch = write = None
     for k, cs in summary.get("pmc_fetch", {}).items():
-        if k.endswith(DOMINANT) and "FETCH_SIZE" in cs:
+        if DOMINANT in k and "FETCH_SIZE" in cs:
             fetch = cs["FETCH_SIZE"]["per_launch"]
     for k, cs in summary.get("pmc_write", {}).items():
-        if k.endswith(DOMINANT) and "WRITE_SIZE" in cs:
+        if DOMINANT in k and "WRITE_SIZE" in cs:
             write = cs["WRITE_SIZE"]["per_launch"]
     if fetch is not None:
         # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB

@@ -396,6 +396,9 @@ bool parse_file(Scanner &in, SceneOut &out)
          if (sscanf(buf.c_str(), " { < %f , %f , %f > < %f , %f , %f > < %f , %f , %f > sample %d color rgb < %f , %f , %f > ",
                     &v1[0], &v1[1], &v1[2], &v2[0], &v2[1], &v2[2], &v3[0], &v3[1], &v3[2], &samples, &c[0], &c[1], &c[2]) != 13)
             return fail("Invalid format for area_light");
+         /* the reference loops whatever the count says (and divides the colour by zero for 0); a count that would make
+          * more than 2^24 lights is refused here instead of being left to run out of memory */
+         if (samples > 4096) return fail("area_light: sample count too large");
          c[0] /= samples * samples; c[1] /= samples * samples; c[2] /= samples * samples;
          float e1[3] = {v3[0] - v2[0], v3[1] - v2[1], v3[2] - v2[2]};
          float e2[3] = {v1[0] - v2[0], v1[1] - v2[1], v1[2] - v2[2]};
@@ -507,6 +510,7 @@ extern "C" int rt_parse_pov(const char *path, rt_scene_desc **out)
    memset(&so.cam, 0, sizeof so.cam);
    if (!parse_file(in, so)) return RT_ERR_PARSE;
    rt_scene_desc *d = (rt_scene_desc *)calloc(1, sizeof(rt_scene_desc));
+   if (!d) { rt_set_error("rt_parse_pov: out of memory"); return RT_ERR_IO; }
    d->camera = so.cam; d->has_camera = so.has_camera ? 1 : 0;
    d->n_spheres = (int32_t)so.spheres.size(); d->spheres = release(so.spheres);
    d->n_triangles = (int32_t)so.triangles.size(); d->triangles = release(so.triangles);
@@ -516,6 +520,11 @@ extern "C" int rt_parse_pov(const char *path, rt_scene_desc **out)
    d->n_lights = (int32_t)so.lights.size(); d->lights = release(so.lights);
    d->n_textures = (int32_t)so.textures.size();
    d->textures = (rt_texture *)calloc(so.textures.size() ? so.textures.size() : 1, sizeof(rt_texture));
+   if (!d->spheres || !d->triangles || !d->boxes || !d->smooth_triangles || !d->planes || !d->lights || !d->textures) {
+      rt_scene_desc_free(d);
+      rt_set_error("rt_parse_pov: out of memory");
+      return RT_ERR_IO;
+   }
    for (std::map<std::string, int>::const_iterator it = so.textures.begin(); it != so.textures.end(); ++it) {
       rt_texture &t = d->textures[it->second];
       /* the reference's sscanf("%s") keeps the closing quote in the name (POVRayParser.cpp:493); it is dropped here */
@@ -543,11 +552,11 @@ extern "C" int rt_load_bmp(const char *path, rt_texture *tex)
    if (fread(data.data(), 1, 3 * n, f) != 3 * n) { fclose(f); rt_set_error("%s is truncated", path); return RT_ERR_PARSE; }
    fclose(f);
    uint8_t *out = (uint8_t *)malloc(4 * n);
+   if (!out) { rt_set_error("rt_load_bmp: out of memory"); return RT_ERR_IO; }
    for (size_t i = 0; i < n; i++) {                                    /* kernel.cu:53-59: BGR -> RGB0, rows as stored */
       out[4 * i] = data[3 * i + 2]; out[4 * i + 1] = data[3 * i + 1]; out[4 * i + 2] = data[3 * i]; out[4 * i + 3] = 0;
    }
-   free(tex->rgba);
-   tex->width = width; tex->height = height; tex->rgba = out;
+   tex->width = width; tex->height = height; tex->rgba = out;      /* whatever tex->rgba pointed to before stays the caller's */
    return RT_OK;
 }
 
