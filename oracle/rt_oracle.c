@@ -245,7 +245,14 @@ static void box_init(geom *g, const rt_box *b)
    g->maxP = biggestCorner(vload(b->p1), vload(b->p2));
 }
 
-/* Sphere.h:42-66 */
+/* Sphere.h:42-66.  The unqualified sqrt(discriminant) at Sphere.h:55,63 has a float argument.  nvcc's device headers
+ * give it the float overload, so the whole expression is binary32: that is what this restatement (and the HIP path)
+ * computes.  A host C++ compile that includes <cmath> without <math.h> finds only ::sqrt(double): the square root,
+ * the subtraction and the division are then done in double and rounded once.  orc_set_sphere_sqrt_double(1) selects
+ * that reading; it exists only to explain ray counts taken from such a host build (a ray in a few hundred thousand
+ * gets a t that differs in the last bit, and a bounce or a shadow decision with it). */
+static int g_sphere_sqrt_double = 0;
+void orc_set_sphere_sqrt_double(int on) { g_sphere_sqrt_double = on; }
 static float sphere_intersects(const geom *g, const ray_t *ray)
 {
    v3 eMinusC = vsub(ray->o, g->c);
@@ -254,6 +261,11 @@ static float sphere_intersects(const geom *g, const ray_t *ray)
       - dDotD * (vdot(eMinusC, eMinusC) - g->r * g->r);
    if (discriminant < 0.0f)
       return -1.0f;
+   if (g_sphere_sqrt_double) {
+      float firstD = (float)(((double)vdot(vneg(ray->d), eMinusC) - sqrt((double)discriminant)) / (double)dDotD);
+      if (isFloatLessThan(0.0f, firstD)) return firstD;
+      return (float)(((double)vdot(vneg(ray->d), eMinusC) + sqrt((double)discriminant)) / (double)dDotD);
+   }
    float firstIntersect = (vdot(vneg(ray->d), eMinusC) - sqrtf(discriminant)) / dDotD;
    if (isFloatLessThan(0.0f, firstIntersect)) {
       return firstIntersect;
@@ -839,7 +851,15 @@ static v3 shader_shade(int shading, v3 matColor, float amb, float dif, float spe
 }
 
 /* ---- shadeObject / getReflection / getRefraction, kernel.cu:202-276, 335-382 */
-typedef struct { const orc_scene *s; int shading; orc_counters *cn; } shade_ctx;
+typedef struct {
+   const orc_scene *s; int shading; orc_counters *cn;
+   uint64_t *sig;     /* when set: a running hash of every decision of the shade tree (which primitive each ray hit or that
+                         it missed, which feelers were shadowed), for orc_interior_mask */
+} shade_ctx;
+static inline void sig_mix(const shade_ctx *cx, uint64_t v)
+{
+   if (cx->sig) { uint64_t h = *cx->sig ^ (v + 0x9e3779b97f4a7c15ULL); h *= 0xbf58476d1ce4e5b9ULL; h ^= h >> 29; *cx->sig = h; }
+}
 
 static v3 shadeObject(const shade_ctx *cx, int invRecLevel, int geomId, float intParam, ray_t ray);
 
@@ -849,6 +869,7 @@ static int isInShadow(const shade_ctx *cx, const ray_t *shadow, float intersectP
    int closestObj = -1;
    if (cx->cn) { cx->cn->rays_shadow++; if (intersectParam == -1.0f) cx->cn->shadow_selfmiss++; }
    getClosestIntersection(cx->s, shadow, &closestObj, &closestIntersect, intersectParam, cx->cn);
+   sig_mix(cx, isFloatLessThan(closestIntersect, intersectParam) ? 0x51ULL : 0x52ULL);
    return isFloatLessThan(closestIntersect, intersectParam);
 }
 
@@ -863,6 +884,7 @@ static v3 getReflection(const shade_ctx *cx, int invRecLevel, v3 point, v3 norma
    float t = FLT_MAX;
    if (cx->cn) cx->cn->rays_reflect++;
    getClosestIntersection(cx->s, &reflectRay, &closestGeom, &t, -FLT_MAX, cx->cn);
+   sig_mix(cx, 0x1000000ULL + (uint64_t)(int64_t)closestGeom);
    if (closestGeom != -1)
       return shadeObject(cx, invRecLevel, closestGeom, t, reflectRay);
    return V(0.0f, 0.0f, 0.0f);
@@ -894,6 +916,7 @@ static v3 getRefraction(const shade_ctx *cx, int invRecLevel, v3 point, v3 norma
       float t = FLT_MAX;
       if (cx->cn) cx->cn->rays_refract++;
       getClosestIntersection(cx->s, &refracRay, &closestGeom, &t, -FLT_MAX, cx->cn);
+      sig_mix(cx, 0x2000000ULL + (uint64_t)(int64_t)closestGeom);
       if (closestGeom != -1)
          return shadeObject(cx, invRecLevel, closestGeom, t, refracRay);
    }
@@ -1002,12 +1025,19 @@ void orc_jitter_uniforms(uint32_t seed, uint32_t index, float *r1, float *r2)
    *r2 = (float)((h2 >> 8) + 1U) * 5.9604644775390625e-8f;
 }
 
+static ray_t camera_ray_at(const orc_scene *s, const orc_params *p, int sroot, int x, int y, float r1, float r2);
 static ray_t camera_ray(const orc_scene *s, const orc_params *p, int sroot, int x, int y)
 {
-   int resWidth = p->width * sroot, resHeight = p->height * sroot;
+   int resWidth = p->width * sroot;
    int index = y * resWidth + x;
    float r1 = 0.5f, r2 = 0.5f;
    if (p->jitter == RT_JITTER_HASH) orc_jitter_uniforms(p->seed, (uint32_t)index, &r1, &r2);
+   return camera_ray_at(s, p, sroot, x, y, r1, r2);
+}
+/* the ray of sample (x, y) for the two uniform draws r1, r2 of kernel.cu:488-489 */
+static ray_t camera_ray_at(const orc_scene *s, const orc_params *p, int sroot, int x, int y, float r1, float r2)
+{
+   int resWidth = p->width * sroot, resHeight = p->height * sroot;
    float uJitter = (r1 - .5f) / (float)resWidth;
    float vJitter = (r2 - .5f) / (float)resHeight;
    float u = 2.0f * (x / (float)resWidth) - 1.0f + uJitter;
@@ -1059,7 +1089,7 @@ void orc_render(const orc_scene *s, const orc_params *p, float *rgb_samples, uin
 #pragma omp parallel
    {
       orc_counters local; memset(&local, 0, sizeof local);
-      shade_ctx cx; cx.s = s; cx.shading = p->shading; cx.cn = c ? &local : NULL;
+      shade_ctx cx; cx.s = s; cx.shading = p->shading; cx.cn = c ? &local : NULL; cx.sig = NULL;
 #pragma omp for schedule(dynamic, 4)
       for (int y = 0; y < resHeight; y++) {
          for (int x = 0; x < resWidth; x++) {
@@ -1106,6 +1136,46 @@ void orc_render(const orc_scene *s, const orc_params *p, float *rgb_samples, uin
       }
    }
    if (!rgb_samples) free(buf);
+}
+
+/* Which pixels of a frame are "interior": in every stratum of the pixel the whole shade tree makes the same decisions
+ * (same primitive or miss for the primary and every bounce ray, same shadowed / lit answer of every feeler) for the
+ * unjittered sample and for eight draws on the boundary of the jitter square (r1, r2 in {0, 0.5, 1}), i.e. (up to features
+ * thinner than half that square) anywhere the reference's random sub-pixel offset can put that sample.  On such pixels a render with another jitter sequence differs only through
+ * smooth shading, so the reference's own images can be compared there with a tight tolerance.
+ * mask: width*height bytes, 1 = interior. */
+void orc_interior_mask(const orc_scene *s, const orc_params *p, uint8_t *mask)
+{
+   int sroot = isqrt_exact(p->sample_count);
+   if (sroot * sroot != p->sample_count) return;
+   int maxRec = p->max_recurse > 0 ? p->max_recurse : K_MAX_RECURSE;
+   /* the centre first, then the corners, then the edge midpoints of the square the two draws span */
+   static const float draws[9][2] = {{0.5f, 0.5f}, {0.0f, 0.0f}, {0.0f, 1.0f}, {1.0f, 0.0f}, {1.0f, 1.0f},
+                                     {0.5f, 0.0f}, {0.5f, 1.0f}, {0.0f, 0.5f}, {1.0f, 0.5f}};
+#ifdef _OPENMP
+   if (p->threads > 0) omp_set_num_threads(p->threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 4)
+   for (int y = 0; y < p->height; y++) {
+      for (int x = 0; x < p->width; x++) {
+         int same = 1;
+         for (int st = 0; st < sroot * sroot && same; st++) {
+            int sx = x * sroot + st % sroot, sy = y * sroot + st / sroot;
+            uint64_t first = 0;
+            for (int k = 0; k < 9 && same; k++) {
+               uint64_t sig = 0;
+               shade_ctx cx; cx.s = s; cx.shading = p->shading; cx.cn = NULL; cx.sig = &sig;
+               ray_t ray = camera_ray_at(s, p, sroot, sx, sy, draws[k][0], draws[k][1]);
+               float t = FLT_MAX; int closestGeom = -1;
+               getClosestIntersection(s, &ray, &closestGeom, &t, -FLT_MAX, NULL);
+               sig_mix(&cx, (uint64_t)(int64_t)closestGeom);
+               if (closestGeom != -1) (void)shadeObject(&cx, maxRec, closestGeom, t, ray);
+               if (k == 0) first = sig; else if (sig != first) same = 0;
+            }
+         }
+         mask[(size_t)y * p->width + x] = (uint8_t)same;
+      }
+   }
 }
 
 /* ---- per-primitive views ------------------------------------------------ */

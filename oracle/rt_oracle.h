@@ -94,6 +94,10 @@ void orc_render(const orc_scene *s, const orc_params *p, float *rgb_samples, uin
 
 /* The two uniform draws of a sample, RT_JITTER_HASH flavour, in (0, 1]. */
 void orc_jitter_uniforms(uint32_t seed, uint32_t index, float *r1, float *r2);
+/* 1: Sphere.h:55,63 read as a host compile without the float sqrt overload does (in double); 0 (default): binary32 */
+void orc_set_sphere_sqrt_double(int on);
+/* 1 per pixel of a 1-sample frame whose shade tree makes the same hit / miss / shadow decisions wherever the jitter puts the sample */
+void orc_interior_mask(const orc_scene *s, const orc_params *p, uint8_t *mask);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,8 @@ def orc():
         lib.orc_camera_ray.argtypes = [vp, C.POINTER(OrcParams), C.c_int, C.c_int, fp, fp]
         lib.orc_render.argtypes = [vp, C.POINTER(OrcParams), vp, vp, vp, vp, C.POINTER(Counters)]
         lib.orc_jitter_uniforms.argtypes = [C.c_uint32, C.c_uint32, fp, fp]
+        lib.orc_set_sphere_sqrt_double.argtypes = [C.c_int]
+        lib.orc_interior_mask.argtypes = [vp, C.POINTER(OrcParams), vp]
         _orc = lib
     return _orc
 
@@ -177,6 +179,13 @@ class OracleScene:
             tb = -3.4028234663852886e38 if to_beat is None else float(to_beat[i])
             prims[i], ts[i] = self.closest(rays[i, 0:3], rays[i, 3:6], tb)
         return prims, ts
+
+    def interior_mask(self, width, height, sample_count=1, shading=abi.RT_PHONG, max_recurse=0, threads=0):
+        """(height, width) bool: pixels whose shade trees make the same decisions wherever the jitter puts their samples."""
+        p = OrcParams(width, height, sample_count, shading, abi.RT_JITTER_NONE, 0, max_recurse, threads)
+        mask = np.zeros((height, width), np.uint8)
+        orc().orc_interior_mask(self.h, C.byref(p), mask.ctypes.data)
+        return mask.astype(bool)
 
     def render(self, width, height, sample_count=1, shading=abi.RT_PHONG, jitter=abi.RT_JITTER_NONE, seed=0,
                max_recurse=0, threads=0, want_samples=True, want_primary=True):

@@ -93,8 +93,10 @@ def test_bvh_sort_trace_matches_reference_output_file():
 # fraction of pixels within 1/255 on every channel that the oracle reaches against the reference's .tga
 # (measured, minus a small margin).  The residue is the reference's cuRAND jitter at silhouettes and its
 # fast-math build; balls2 is a fractal of 7381 small spheres, nearly all silhouette.
-TGA_FLOOR = {"recurse_simp2": 0.995, "valentine": 0.995, "final1": 0.995, "simple_refract": 0.985, "bunny": 0.96,
-             "dragon_large_tris": 0.945, "balls2": 0.83}
+TGA_FLOOR = {"recurse_simp2": 0.995, "valentine": 0.995, "final1": 0.995, "simple_refract": 0.985, "bunny": 0.985,
+             "dragon_large_tris": 0.98, "balls2": 0.83}
+# samples per pixel the image was made with: the two meshes agree best with a 9-sample render (tests/test_oracle_composition.py)
+TGA_SPP = {"bunny": 9, "dragon_large_tris": 9}
 
 
 @pytest.mark.parametrize("name", sorted(TGA_FLOOR))
@@ -103,7 +105,7 @@ def test_render_against_reference_tga(name):
     h, w = want.shape[:2]
     osc = orclib.OracleScene(scene(name))
     try:
-        got = osc.render(w, h, 1, abi.RT_PHONG, abi.RT_JITTER_NONE, 0, 0, 0, want_samples=False, want_primary=False)["rgba"]
+        got = osc.render(w, h, TGA_SPP.get(name, 1), abi.RT_PHONG, abi.RT_JITTER_NONE, 0, 0, 0, want_samples=False, want_primary=False)["rgba"]
     finally:
         osc.close()
     diff = np.abs(got[:, :, :3].astype(np.int16) - want.astype(np.int16)).max(axis=2)
