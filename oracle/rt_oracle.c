@@ -1178,6 +1178,34 @@ void orc_interior_mask(const orc_scene *s, const orc_params *p, uint8_t *mask)
    }
 }
 
+/* The nearest intersection of every primary ray with no tree at all: every BVH primitive and every plane is tested and
+ * the smallest accepted parameter kept (accepted as kernel.cu:124-126 accepts: above -EPSILON).  No tie rule and no
+ * visiting order, so this is not what the reference reports where hits lie within EQUAL_EPSILON of each other; it is
+ * the ground truth a tree of any shape is checked against: a tree that lost a primitive or fitted a box too small
+ * reports a larger t (or a miss) somewhere.  prim / t: one entry per sample, row-major. */
+void orc_brute_primary(const orc_scene *s, const orc_params *p, int32_t *prim, float *tout)
+{
+   int sroot = isqrt_exact(p->sample_count);
+   if (sroot * sroot != p->sample_count) return;
+   int resWidth = p->width * sroot, resHeight = p->height * sroot;
+#ifdef _OPENMP
+   if (p->threads > 0) omp_set_num_threads(p->threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+   for (int y = 0; y < resHeight; y++) {
+      for (int x = 0; x < resWidth; x++) {
+         ray_t ray = camera_ray(s, p, sroot, x, y);
+         float t = FLT_MAX; int best = -1;
+         for (int g = 0; g < s->n_geom + s->n_planes; g++) {
+            float dist = geom_getIntersection(geom_by_id(s, g), &ray);
+            if (dist < t && isFloatAboveZero(dist)) { t = dist; best = g; }
+         }
+         size_t index = (size_t)y * resWidth + x;
+         prim[index] = best; tout[index] = t;
+      }
+   }
+}
+
 /* ---- per-primitive views ------------------------------------------------ */
 float orc_prim_intersect(const orc_scene *s, int32_t prim, const float o[3], const float d[3])
 {

@@ -98,6 +98,8 @@ void orc_jitter_uniforms(uint32_t seed, uint32_t index, float *r1, float *r2);
 void orc_set_sphere_sqrt_double(int on);
 /* 1 per pixel of a 1-sample frame whose shade tree makes the same hit / miss / shadow decisions wherever the jitter puts the sample */
 void orc_interior_mask(const orc_scene *s, const orc_params *p, uint8_t *mask);
+/* nearest intersection of every primary ray by testing every primitive and plane, no tree */
+void orc_brute_primary(const orc_scene *s, const orc_params *p, int32_t *prim, float *t);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,7 @@ def orc():
         lib.orc_jitter_uniforms.argtypes = [C.c_uint32, C.c_uint32, fp, fp]
         lib.orc_set_sphere_sqrt_double.argtypes = [C.c_int]
         lib.orc_interior_mask.argtypes = [vp, C.POINTER(OrcParams), vp]
+        lib.orc_brute_primary.argtypes = [vp, C.POINTER(OrcParams), vp, vp]
         _orc = lib
     return _orc
 
@@ -179,6 +180,15 @@ class OracleScene:
             tb = -3.4028234663852886e38 if to_beat is None else float(to_beat[i])
             prims[i], ts[i] = self.closest(rays[i, 0:3], rays[i, 3:6], tb)
         return prims, ts
+
+    def brute_primary(self, width, height, sample_count=1, jitter=abi.RT_JITTER_NONE, seed=0, threads=0):
+        """(prim, t) of every primary ray with no tree: every primitive and plane tested, the nearest kept."""
+        s = int(round(sample_count ** 0.5))
+        n = width * s * height * s
+        p = OrcParams(width, height, sample_count, abi.RT_PHONG, jitter, seed, 0, threads)
+        prim, t = np.full(n, -2, np.int32), np.zeros(n, np.float32)
+        orc().orc_brute_primary(self.h, C.byref(p), prim.ctypes.data, t.ctypes.data)
+        return prim, t
 
     def interior_mask(self, width, height, sample_count=1, shading=abi.RT_PHONG, max_recurse=0, threads=0):
         """(height, width) bool: pixels whose shade trees make the same decisions wherever the jitter puts their samples."""

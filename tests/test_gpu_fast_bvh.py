@@ -15,6 +15,7 @@ import os
 import numpy as np
 import pytest
 
+import orclib
 import raytracer_amd as ra
 from raytracer_amd import abi, synth
 
@@ -50,6 +51,42 @@ def test_fast_tree_agrees_with_reference_tree(name, builder):
     visits0 = st0["node_visits"] + st0["node_visits_shadow"]
     visits1 = st1["node_visits"] + st1["node_visits_shadow"]
     assert visits1 < visits0
+
+
+def check_against_brute_force(sd, w, h, builder):
+    """Primary rays of a fast tree against the oracle's brute-force nearest hit (every primitive tested, no tree):
+    hit / miss must agree on every sample and t must lie within the reference's tie window above the true minimum.
+    A tree that lost a primitive, or fitted a box too small, fails this somewhere; a comparison with the product's own
+    reference-tree output would not notice a fault both share."""
+    osc = orclib.OracleScene(sd)
+    try:
+        prim_b, t_b = osc.brute_primary(w, h)
+    finally:
+        osc.close()
+    with ra.Scene(sd, **{builder: True}) as sc:
+        prim, t = sc.trace_primary(w, h)
+    hit, hit_b = prim >= 0, prim_b >= 0
+    assert np.array_equal(hit, hit_b), f"{int((hit != hit_b).sum())} samples disagree on hit / miss"
+    d = t[hit] - t_b[hit]
+    assert d.min() >= -1e-4 and d.max() <= 0.0101, (float(d.min()), float(d.max()))       # EQUAL_EPSILON, Util.h:6
+    return float((prim == prim_b).mean())
+
+
+@pytest.mark.parametrize("builder", ["fast_bvh", "gpu_bvh"])
+@pytest.mark.parametrize("name", ["cornell", "balls2", "bunny", "iceBot", "dragon_large_tris", "box", "transforms"])
+def test_fast_tree_against_brute_force(name, builder):
+    """One scene at least per primitive class: spheres with transforms (balls2, transforms), boxes (box, cornell), flat
+    triangles (bunny, dragon), smooth triangles (iceBot), planes (cornell, iceBot, dragon)."""
+    sd = ra.SceneData.load(os.path.join(GOLDEN, "scenes", name + ".npz"))
+    same = check_against_brute_force(sd, 160, 120, builder)
+    print(f"{name} [{builder}]: nearest primitive equal on {same:.4f} of the samples")
+    assert same >= 0.99
+
+
+@pytest.mark.parametrize("builder", ["fast_bvh", "gpu_bvh"])
+def test_fast_tree_of_a_million_triangles_against_brute_force(builder):
+    sd = synth.terrain(1000, 500, lights_per_side=1)
+    check_against_brute_force(sd, 48, 27, builder)
 
 
 def test_fast_tree_makes_the_large_height_field_tractable():

@@ -67,6 +67,24 @@ def test_ray_counts_of_the_host_compiled_reference(name):
             orclib.orc().orc_set_sphere_sqrt_double(0)
 
 
+@pytest.mark.parametrize("name", ["cornell", "balls2", "bunny", "iceBot", "dragon_large_tris", "box", "final2", "transforms"])
+def test_reference_tree_walk_against_brute_force(name):
+    """The oracle's walk of the reference tree never loses a hit: against the nearest intersection found by testing every
+    primitive and plane, hit / miss is the same on every primary ray and t lies within the tie window
+    (EQUAL_EPSILON, Util.h:6; kernel.cu:108-122 may keep the farther of two hits that close) above the minimum."""
+    osc = orclib.OracleScene(scene(name))
+    try:
+        prim_b, t_b = osc.brute_primary(160, 120)
+        r = osc.render(160, 120, 1, abi.RT_PHONG, abi.RT_JITTER_NONE, 0, 0, 0, want_samples=False, want_primary=True)
+    finally:
+        osc.close()
+    hit, hit_b = r["prim"] >= 0, prim_b >= 0
+    assert np.array_equal(hit, hit_b)
+    d = r["t"][hit] - t_b[hit]
+    assert d.min() >= -1e-4 and d.max() < 0.01
+    assert (r["prim"] == prim_b).mean() >= 0.99
+
+
 # scene: (samples per pixel the image was made with, floor of interior pixels within 2/255, floor of the interior share)
 INTERIOR = {
     "recurse_simp2": (1, 0.9999, 0.97),
