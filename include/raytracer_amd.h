@@ -269,6 +269,23 @@ int rt_tile_count(int width, int height, int tile_first, int tile_stride);
 int rt_untile_device(const void *tiles_dev, size_t part_stride_bytes, int n_parts,
                      int width, int height, void *frame_dev, void *stream);
 
+/* ---- one frame on several devices --------------------------------------- */
+/* The reference renders on one device (kernel.cu:689-761); its samples are independent (kernel.cu:484-543), so a
+ * frame shards by tiles.  An rt_multi holds one replica of the scene per entry of `devices` (NULL: devices 0 ..
+ * n_devices-1; a device may be listed more than once, its parts then share it).  rt_multi_render renders tile k of
+ * the RT_TILE grid on part k mod n_devices, gathers the parts' compact tile buffers on the first device with direct
+ * peer copies, un-tiles them there and copies the frame to the host: the same bytes rt_render produces.
+ * params->tile_first / tile_stride / out_layout are ignored.  stats (may be NULL): counts summed over the parts,
+ * times the maximum over the parts.  One frame at a time per rt_multi. */
+typedef struct rt_multi rt_multi;
+int rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_devices, int flags, rt_multi **out);
+void rt_multi_destroy(rt_multi *multi);
+int rt_multi_device_count(const rt_multi *multi);
+int rt_multi_set_camera(rt_multi *multi, const rt_camera *camera);
+int rt_multi_render(rt_multi *multi, const rt_render_params *params, uint8_t *out_rgba_host, rt_stats *stats);
+/* the same, the frame left in memory of the first device (out_rgba_dev: width*height*4 bytes there) */
+int rt_multi_render_device(rt_multi *multi, const rt_render_params *params, void *out_rgba_dev, rt_stats *stats);
+
 /* Parity/debug views of the same kernels.
  * Per-sample closest hit of the primary rays (the first getClosestIntersection
  * of rayTrace, kernel.cu:531): prim_ids[i] (-1 = miss) and t[i] for sample

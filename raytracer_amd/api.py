@@ -180,6 +180,59 @@ class Scene:
         return rgb, st.as_dict()
 
 
+class MultiScene:
+    """One frame on several devices (rt_multi_*): a scene replica per entry of `devices`, tiles dealt round-robin,
+    compact tile buffers gathered on the first device, un-tiled there.  A device may be listed more than once."""
+
+    def __init__(self, data: SceneData, devices, counters=False, fast_bvh=False):
+        self._lib = abi.load_library()
+        desc, keep = data.to_desc()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        flags = (abi.RT_SCENE_COUNTERS if counters else 0) | (abi.RT_SCENE_FAST_BVH if fast_bvh else 0)
+        _check(self._lib, self._lib.rt_multi_create(C.byref(desc), devs, len(devices), flags, C.byref(h)))
+        self._h = h
+        del keep
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def device_count(self):
+        return self._lib.rt_multi_device_count(self._h)
+
+    def set_camera(self, pos, up, right, look_at):
+        cam = abi.Camera()
+        for k, v in (("pos", pos), ("up", up), ("right", right), ("look_at", look_at)):
+            getattr(cam, k)[:] = [float(x) for x in v]
+        _check(self._lib, self._lib.rt_multi_set_camera(self._h, C.byref(cam)))
+
+    def render(self, width, height, sample_count=1, shading=PHONG, jitter=abi.RT_JITTER_HASH, seed=0, max_recurse=0):
+        p = make_params(width, height, sample_count, shading, jitter, seed, max_recurse)
+        out = np.zeros((height, width, 4), np.uint8)
+        st = abi.Stats()
+        _check(self._lib, self._lib.rt_multi_render(self._h, C.byref(p), out.ctypes.data, C.byref(st)))
+        return out, st.as_dict()
+
+    def render_device(self, params, out_ptr):
+        st = abi.Stats()
+        _check(self._lib, self._lib.rt_multi_render_device(self._h, C.byref(params), C.c_void_p(out_ptr), C.byref(st)))
+        return st.as_dict()
+
+
 def tile_count(width, height, tile_first=0, tile_stride=1):
     return abi.load_library().rt_tile_count(width, height, tile_first, tile_stride)
 

@@ -99,15 +99,35 @@ extern "C" void launch_kernel(TKSceneData *data, ShadingType stype, int width, i
 
    const char *dev_env = getenv("RT_DEVICE");
    const char *jit_env = getenv("RT_JITTER");
-   rt_scene *scene = NULL;
-   if (rt_scene_create(&d, dev_env ? atoi(dev_env) : 0, RT_SCENE_DEFAULT, &scene) != RT_OK) { free(blitz.rgba); die("scene set-up failed"); }
+   /* RT_DEVICES = "0,1,2,3": the frame is split over those devices (rt_multi_render) */
+   std::vector<int> devices;
+   if (const char *list = getenv("RT_DEVICES")) {
+      for (const char *c = list; *c;) {
+         char *end = NULL;
+         long v = strtol(c, &end, 10);
+         if (end == c) break;
+         devices.push_back((int)v);
+         c = *end == ',' ? end + 1 : end;
+      }
+   }
    rt_render_params p; memset(&p, 0, sizeof p);
    p.width = width; p.height = height; p.sample_count = sampleCount;
    p.shading = stype == COOK_TORRANCE ? RT_COOK_TORRANCE : RT_PHONG;
    p.jitter = (jit_env && atoi(jit_env) == 0) ? RT_JITTER_NONE : RT_JITTER_HASH;
    p.seed = 0; p.max_recurse = RT_MAX_RECURSE; p.tile_first = 0; p.tile_stride = 1; p.out_layout = RT_OUT_FRAME;
-   int rc = rt_render(scene, &p, (uint8_t *)output, NULL);
-   rt_scene_destroy(scene);
+   int rc;
+   if (devices.size() > 1) {
+      rt_multi *multi = NULL;
+      if (rt_multi_create(&d, devices.data(), (int)devices.size(), RT_SCENE_DEFAULT, &multi) != RT_OK) { free(blitz.rgba); die("scene set-up failed"); }
+      rc = rt_multi_render(multi, &p, (uint8_t *)output, NULL);
+      rt_multi_destroy(multi);
+   } else {
+      rt_scene *scene = NULL;
+      const int device = !devices.empty() ? devices[0] : dev_env ? atoi(dev_env) : 0;
+      if (rt_scene_create(&d, device, RT_SCENE_DEFAULT, &scene) != RT_OK) { free(blitz.rgba); die("scene set-up failed"); }
+      rc = rt_render(scene, &p, (uint8_t *)output, NULL);
+      rt_scene_destroy(scene);
+   }
    free(blitz.rgba);
    if (rc != RT_OK) die("RayTrace kernel failed");
 }

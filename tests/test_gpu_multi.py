@@ -1,0 +1,75 @@
+"""The multi-device frame driver behind the C ABI (rt_multi_*): a scene replica per part, tiles dealt round-robin,
+compact tile buffers gathered on the first device, un-tiled there.  Tiles are disjoint and nothing is reduced, so the
+frame must be the bytes rt_render produces on one device.  On a one-GPU machine the parts share the device (the same
+device listed several times), which exercises everything but the peer copies between different devices."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import raytracer_amd as ra
+from raytracer_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden", "scenes")
+
+
+def devices_for(n):
+    have = ra.device_count()
+    return [k % have for k in range(n)]
+
+
+@pytest.mark.parametrize("name, w, h, spp, shading", [("cornell", 333, 257, 1, ra.PHONG), ("balls2", 640, 360, 1, ra.PHONG),
+                                                     ("bunny", 320, 200, 4, ra.COOK_TORRANCE), ("simple", 31, 17, 9, ra.PHONG)])
+@pytest.mark.parametrize("parts", [1, 2, 3, 8])
+def test_multi_frame_equals_single_device_frame(name, w, h, spp, shading, parts):
+    sd = ra.SceneData.load(os.path.join(G, name + ".npz"))
+    with ra.Scene(sd) as sc:
+        want, st0 = sc.render(w, h, spp, shading, abi.RT_JITTER_HASH, seed=7)
+    with ra.MultiScene(sd, devices_for(parts)) as ms:
+        assert ms.device_count() == parts
+        got, st1 = ms.render(w, h, spp, shading, abi.RT_JITTER_HASH, seed=7)
+        again, _ = ms.render(w, h, spp, shading, abi.RT_JITTER_HASH, seed=7)
+    assert np.array_equal(got, want)
+    assert np.array_equal(again, want)
+    for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "rays_total", "shade_nodes"):
+        assert st1[k] == st0[k], k
+
+
+def test_multi_camera_and_errors():
+    sd = ra.SceneData.load(os.path.join(G, "cornell.npz"))
+    cam = ([0.5, 1.5, 9.0], [0, 1, 0], [1.3333, 0, 0], [0, 0.5, 0])
+    with ra.Scene(sd) as sc:
+        sc.set_camera(*cam)
+        want, _ = sc.render(200, 150, 1, ra.PHONG, abi.RT_JITTER_NONE)
+    with ra.MultiScene(sd, devices_for(4)) as ms:
+        ms.set_camera(*cam)
+        got, _ = ms.render(200, 150, 1, ra.PHONG, abi.RT_JITTER_NONE)
+        assert np.array_equal(got, want)
+        with pytest.raises(ra.RaytracerError) as e:
+            ms.render(64, 48, 3)
+        assert e.value.code == abi.RT_ERR_BAD_SAMPLE_COUNT
+        got2, _ = ms.render(200, 150, 1, ra.PHONG, abi.RT_JITTER_NONE)           # still usable after an error
+        assert np.array_equal(got2, want)
+    with pytest.raises(ra.RaytracerError) as e:
+        ra.MultiScene(sd, [0, ra.device_count()])
+    assert e.value.code == abi.RT_ERR_BAD_ARGUMENT
+
+
+def test_cli_and_drop_in_split_a_frame(tmp_path):
+    exe = os.path.join(ROOT, "raytracer_amd", "raytrace")
+    pov = os.path.join(ROOT, "tests", "golden", "pov", "grammar_mix.pov")
+    one, many = tmp_path / "one.tga", tmp_path / "many.tga"
+    for out, extra in ((one, []), (many, ["-g", "3"])):
+        r = subprocess.run([exe, "200", "120", "-I", pov, "-O", str(out), *extra], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+    assert open(one, "rb").read() == open(many, "rb").read()
+    dropin = os.path.join(ROOT, "tests", "dropin", "dropin_main")
+    a, b = tmp_path / "a.rgba", tmp_path / "b.rgba"
+    for out, env in ((a, {}), (b, {"RT_DEVICES": "0,0"})):
+        r = subprocess.run([dropin, str(out), "160", "120", "1", "phong"], capture_output=True, text=True, timeout=120, env={**os.environ, **env})
+        assert r.returncode == 0, r.stdout + r.stderr
+    assert open(a, "rb").read() == open(b, "rb").read()
