@@ -143,3 +143,52 @@ def test_random_scenes_axis_aligned_view(seed):
     sd = synth.random_scene(seed, n_spheres=40, n_triangles=30, n_boxes=20, n_smooth=10)
     sd.camera = dict(sd.camera, pos=np.array([0, 0, 7], np.float32), look_at=np.array([0, 0, 0], np.float32))
     compare(sd, 65, 49, jitter=abi.RT_JITTER_NONE, rgb_tol=1e-3)
+
+
+def test_million_triangles_256_lights_in_chunks():
+    """The largest configuration's scene (1 000 000 triangles, 256 point lights) at a reduced frame, 4 samples per pixel,
+    forced into several chunks of tiles.  The oracle cannot walk this scene in test time (its reference tree costs ~10^4
+    box tests per ray here; the many-light comparison with the oracle is test_256_lights above, the nearest-hit check
+    of this tree against brute force is in test_gpu_fast_bvh.py), so what is checked are the properties that do not
+    depend on size: the same bytes twice, the same bytes whatever the chunking, the same bytes from 2 and 8 tile
+    partitions, ray counts that add up, and the counting variant of the kernel producing the same frame."""
+    sd = synth.terrain(1000, 500)
+    w, h, spp = 256, 144, 4
+    keep = {k: os.environ.get(k) for k in ("RT_CHUNK_TILES",)}
+    try:
+        with ra.Scene(sd, fast_bvh=True) as sc:
+            info = sc.info()
+            assert info["n_bvh_prims"] == 1_000_000 and info["n_lights"] == 256 and info["tree_depth"] > 14     # deeper than the LDS stack
+            whole, st = sc.render(w, h, spp, abi.RT_PHONG, abi.RT_JITTER_HASH, seed=3)
+            assert st["launches_trace"] == 1
+            os.environ["RT_CHUNK_TILES"] = "7"
+            chunked, st_c = sc.render(w, h, spp, abi.RT_PHONG, abi.RT_JITTER_HASH, seed=3)
+            again, _ = sc.render(w, h, spp, abi.RT_PHONG, abi.RT_JITTER_HASH, seed=3)
+            assert st_c["launches_trace"] == 6                     # 40 tiles in chunks of 7
+            assert chunked.tobytes() == whole.tobytes() and again.tobytes() == whole.tobytes()
+            for k in ("rays_primary", "rays_shadow", "rays_reflect", "shade_nodes", "shadow_skipped", "rays_total"):
+                assert st_c[k] == st[k], k
+            assert st["rays_shadow"] + st["shadow_skipped"] == 256 * st["shade_nodes"]
+            assert st["rays_primary"] == w * h * spp and st["rays_reflect"] > 0
+            for parts in (2, 8):
+                total = np.zeros_like(whole)
+                rays = 0
+                for k in range(parts):
+                    part, st_k = sc.render(w, h, spp, abi.RT_PHONG, abi.RT_JITTER_HASH, seed=3, tile_first=k, tile_stride=parts)
+                    assert not (total[:, :, 3] & part[:, :, 3]).any()            # tiles are disjoint (alpha is 255 where written)
+                    total |= part
+                    rays += st_k["rays_total"]
+                assert total.tobytes() == whole.tobytes()
+                assert rays == st["rays_total"]
+        os.environ.pop("RT_CHUNK_TILES", None)
+        with ra.Scene(sd, fast_bvh=True, counters=True) as sc:
+            counted, st_n = sc.render(w, h, spp, abi.RT_PHONG, abi.RT_JITTER_HASH, seed=3)
+        assert counted.tobytes() == whole.tobytes()
+        assert st_n["node_visits_shadow"] > 0 and st_n["rays_total"] == st["rays_total"]
+        assert len(np.unique(whole[:, :, :3].reshape(-1, 3), axis=0)) > 1000
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
