@@ -185,7 +185,7 @@ typedef struct rt_scene_info {
    uint64_t device_bytes;
    float ms_build_host, ms_upload;
    float ms_build_device;    /* RT_SCENE_GPU_BVH: the device kernels of the tree build (ms_build_host then covers the rest) */
-   int32_t pad;
+   int32_t filter_depth;     /* levels of the miss filter's tree, 0 when the scene has none */
 } rt_scene_info;
 
 /* Flattened BVH node, 64 bytes: both children's boxes live in the parent so
@@ -209,6 +209,9 @@ enum {
                               * Far fewer box tests per ray, but near-ties between primitives (kernel.cu:108-122)
                               * are resolved by visiting order, so a few silhouette samples differ from the
                               * reference; never part of a parity claim */
+   RT_SCENE_NO_FILTER = 8,   /* do not build the miss filter (a second, widened tree that only serves to prove that a ray
+                              * meets no primitive, so that the reference's tree need not be walked for it); results are
+                              * the same with and without it */
    RT_SCENE_GPU_BVH = 4      /* NOT the reference's tree either: a linear BVH (Morton codes + radix tree) built on the
                               * device in milliseconds; same caveat as RT_SCENE_FAST_BVH, lower tree quality, for scenes
                               * that change every frame.  Ignored by rt_scene_create_host */

@@ -30,7 +30,7 @@ RT_OUT_FRAME, RT_OUT_TILES = 0, 1
 RT_TILE = 32
 RT_MAX_RECURSE = 6
 RT_TRACE_RAYS_STATIC_MAX = 524288
-RT_SCENE_DEFAULT, RT_SCENE_COUNTERS, RT_SCENE_FAST_BVH, RT_SCENE_GPU_BVH = 0, 1, 2, 4
+RT_SCENE_DEFAULT, RT_SCENE_COUNTERS, RT_SCENE_FAST_BVH, RT_SCENE_GPU_BVH, RT_SCENE_NO_FILTER = 0, 1, 2, 4, 8
 
 f32, i32 = np.float32, np.int32
 
@@ -105,7 +105,7 @@ class SceneInfo(C.Structure):
                 ("n_nodes", C.c_int32), ("n_materials", C.c_int32), ("tree_depth", C.c_int32),
                 ("root", C.c_int32), ("device_bytes", C.c_uint64),
                 ("ms_build_host", C.c_float), ("ms_upload", C.c_float),
-                ("ms_build_device", C.c_float), ("pad", C.c_int32)]
+                ("ms_build_device", C.c_float), ("filter_depth", C.c_int32)]
 
 
 # every symbol include/raytracer_amd.h and include/raytracer_tokens.h declare

@@ -18,6 +18,8 @@ enum { RT_PRIM_SPHERE = 0, RT_PRIM_TRIANGLE = 1, RT_PRIM_BOX = 2, RT_PRIM_SMOOTH
 #define RT_FLAG_XFORM 1u      /* inv_trans is not the identity: the ray must be transformed (Geometry.h:16-18) */
 
 #define RT_ROOT_EMPTY INT32_MIN
+#define RT_FILTER_DEPTH 16       /* levels the miss filter's tree may have before the primitive count forces more */
+#define RT_FILTER_MIN_PRIMS 64   /* scenes smaller than this get no miss filter: their reference tree is a handful of boxes */
 
 /* Intersection record.
  *   sphere   g[0..2] centre, g[3] radius                          (Sphere.h:42-66)
@@ -69,6 +71,8 @@ typedef struct rt_flat_scene {
    int32_t n_prims, n_planes, n_lights, n_nodes, n_materials;
    int32_t root, tree_depth;
    rt_bvh_node *nodes;         /* n_nodes */
+   rt_bvh_node *filter_nodes;  /* n_filter_nodes: the miss filter's tree (root 0), or none; leaves refer to primitive ids like `nodes` */
+   int32_t n_filter_nodes, filter_depth;
    rt_dev_prim *prims;         /* n_prims, indexed by primitive id */
    rt_dev_xform *xforms;       /* n_prims */
    rt_dev_shade *shades;       /* n_prims */

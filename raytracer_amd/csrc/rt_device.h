@@ -160,9 +160,11 @@ __device__ __forceinline__ float slab_literal(const Ray &r, float mnx, float mny
  *    -FLT_MAX / FLT_MAX pair (neutral in max3/min3), a miss when the origin is outside the slab, and
  *    its strict coordinate test to "inside".  Whatever rt_div made of the tiny or zero direction is
  *    discarded by the selects.  PAR = false is the same function for a wave that holds no such ray. */
+/* the two numbers the box test turns on: where the ray enters the last of the three slabs (A) and where it leaves the
+ * first (B), with the reference's treatment of parallel axes; miss / strict as described above */
+struct SlabAB { float A, B; bool miss, strict; };
 template <bool PAR>
-__device__ __forceinline__ float slab_fast(const RayCtx &c, float mnx, float mny, float mnz,
-                                           float mxx, float mxy, float mxz)
+__device__ __forceinline__ SlabAB slab_ab(const RayCtx &c, float mnx, float mny, float mnz, float mxx, float mxy, float mxz)
 {
    const Ray &r = c.r;
    float x1 = rt_div(mnx - r.o.x, r.d.x, c.yx), x2 = rt_div(mxx - r.o.x, r.d.x, c.yx);
@@ -171,21 +173,40 @@ __device__ __forceinline__ float slab_fast(const RayCtx &c, float mnx, float mny
    float xl = fminf(x1, x2), xh = fmaxf(x1, x2);
    float yl = fminf(y1, y2), yh = fmaxf(y1, y2);
    float zl = fminf(z1, z2), zh = fmaxf(z1, z2);
-   bool miss = false, strict = true;
+   SlabAB s; s.miss = false; s.strict = true;
    if (PAR) {
       bool px = (c.par & 1u) != 0, py = (c.par & 2u) != 0, pz = (c.par & 4u) != 0;
       xl = px ? -FLT_MAX : xl; xh = px ? FLT_MAX : xh;
       yl = py ? -FLT_MAX : yl; yh = py ? FLT_MAX : yh;
       zl = pz ? -FLT_MAX : zl; zh = pz ? FLT_MAX : zh;
-      miss = (px && (r.o.x < mnx || r.o.x > mxx)) || (py && (r.o.y < mny || r.o.y > mxy)) ||
-             (pz && (r.o.z < mnz || r.o.z > mxz));
-      strict = (!px || (r.o.x > mnx && r.o.x < mxx)) && (!py || (r.o.y > mny && r.o.y < mxy)) &&
-               (!pz || (r.o.z > mnz && r.o.z < mxz));
+      s.miss = (px && (r.o.x < mnx || r.o.x > mxx)) || (py && (r.o.y < mny || r.o.y > mxy)) ||
+               (pz && (r.o.z < mnz || r.o.z > mxz));
+      s.strict = (!px || (r.o.x > mnx && r.o.x < mxx)) && (!py || (r.o.y > mny && r.o.y < mxy)) &&
+                 (!pz || (r.o.z > mnz && r.o.z < mxz));
    }
-   float A = fmaxf(fmaxf(xl, yl), zl);
-   float B = fminf(fminf(xh, yh), zh);
-   float res = (A < 0.0f && B > 0.0f && strict) ? B : (A < B ? A : -1.0f);
-   return miss ? -1.0f : res;
+   s.A = fmaxf(fmaxf(xl, yl), zl);
+   s.B = fminf(fminf(xh, yh), zh);
+   return s;
+}
+/* the reference's answer from those two numbers */
+__device__ __forceinline__ float slab_value(const SlabAB &s)
+{
+   float res = (s.A < 0.0f && s.B > 0.0f && s.strict) ? s.B : (s.A < s.B ? s.A : -1.0f);
+   return s.miss ? -1.0f : res;
+}
+template <bool PAR>
+__device__ __forceinline__ float slab_fast(const RayCtx &c, float mnx, float mny, float mnz,
+                                           float mxx, float mxy, float mxz)
+{
+   return slab_value(slab_ab<PAR>(c, mnx, mny, mnz, mxx, mxy, mxz));
+}
+/* The miss filter's reading of the same two numbers: could the ray meet anything inside this (widened) box at a
+ * parameter the reference would accept (above -EPSILON)?  Yes unless the ray's line misses the box or the box lies
+ * wholly behind that; the answer is where the ray enters it (0 from inside), for near-first order, or -1.  Unlike the
+ * reference's value this never turns away a box the origin sits in or just in front of. */
+__device__ __forceinline__ float slab_filter_value(const SlabAB &s)
+{
+   return (!s.miss && s.A <= s.B && s.B > -2.0f * RT_EPS) ? fmaxf(s.A, 0.0f) : -1.0f;
 }
 
 /* Sphere::intersects, Sphere.h:42-66 (ray already in object space) */

@@ -59,6 +59,7 @@ struct DScene {
    const uchar4 *texels;
    const int *prim_ids;     /* primitive id (the caller's numbering) of device primitive k; see rt_scene_create */
    int n_prims, n_planes, n_lights, root;
+   int filter_root;  /* node index of the miss filter's root, or RT_ROOT_EMPTY when the scene has none */
    int fast_ok;      /* every BVH bound is finite and below 2^40 in magnitude */
    int any_xform;    /* some BVH primitive carries a transform */
 };
@@ -364,7 +365,8 @@ __device__ __forceinline__ Ray camera_ray(const DCamera &cam, const DGrid &g, in
  *            No data is handed between waves, so there is nothing to wait for and every wave's exit is its
  *            own: primaries dry, list empty, lanes idle. */
 enum { OUT_HIT = 0, OUT_CHAIN = 2 };
-enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2 };
+enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2, MODE_KIND = 3,
+       MODE_FILTER = 4 };   /* set while the ray is still in the miss filter's tree (see enter_tree below) */
 #define RT_SHADOW_ITEM 0x80000000u
 
 #define RT_STEP_CAP (1ULL << 28)
@@ -372,12 +374,13 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2 };
 #define RT_CUR_IDLE ((int)0x80000000)
 #define RT_LIST_CAP_FIRST 1024u   /* entries of a wave's list to begin with; doubled when a frame overflows it */
 #define RT_LIST_CAP_MAX 65536u
-#define RT_NODE_BURST 16    /* node steps between two leaf steps / refill checks */
+#define RT_NODE_BURST 8     /* most node steps between two leaf steps / refill checks */
+#define RT_LEAF_TRIGGER 24  /* lanes waiting at a leaf that end a burst of node steps early */
 #define RT_FETCH_STREAMS 64u /* counters the primaries are handed out through */
 #define RT_CTR_WORDS (8 * ((int)RT_FETCH_STREAMS + 1))   /* 64-bit words of a launch's counters: the streams' (64 bytes apart), then the queue tail */
 #define RT_ORDER_CLASSES 64 /* classes of tile cost that decide the order in which a frame's tiles are started */
 #define RT_ORDER_MEAN_WEIGHT 4
-#define RT_LDS_STACK 14     /* stack entries per lane kept in LDS; deeper trees spill the rest to global memory */
+#define RT_LDS_STACK 16     /* stack entries per lane kept in LDS; deeper trees spill the rest to global memory */
 #define RT_RESERVE 256      /* queue entries a wave reserves at a time for the bounce rays it spawns */
 
 struct TraceArgs {
@@ -388,7 +391,8 @@ struct TraceArgs {
    unsigned flag_stride;
    unsigned long long *next;    /* this launch's zeroed fetch counters: RT_FETCH_STREAMS of them, 64 bytes apart */
    unsigned long long *stats;
-   int refill_idle, node_burst; /* tuning: idle lanes that trigger a refill, node steps between two leaf steps */
+   int refill_idle, node_burst; /* tuning: idle lanes that trigger a refill, most node steps between two leaf steps */
+   int leaf_trigger;            /* tuning: lanes waiting at a leaf that end a burst of node steps early */
    unsigned reserve;            /* OUT_CHAIN: queue entries a wave reserves per atomic for the bounce rays it spawns */
    /* OUT_CHAIN */
    DCamera cam;                 /* the first n entries are the primaries of grid `g`: made here, on fetch */
@@ -497,12 +501,16 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    const int stride = RT_BLOCK;
    StackEntry *const spill = SPILL ? a.spill + ((size_t)blockIdx.x * RT_BLOCK + threadIdx.x) : nullptr;
    const size_t spill_stride = SPILL ? (size_t)gridDim.x * RT_BLOCK : 0;
+   /* (the empty asm statements keep the two loads apart: merged into one load through a generic pointer they cost more,
+    * and the compiler's check of which address space that pointer is in does not assemble for gfx950) */
    auto stack_get = [&](int i) {
-      if (SPILL && i >= RT_LDS_STACK) return spill[(size_t)(i - RT_LDS_STACK) * spill_stride];
-      return stack[i * stride];
+      StackEntry e;
+      if (SPILL && i >= RT_LDS_STACK) { e = spill[(size_t)(i - RT_LDS_STACK) * spill_stride]; asm volatile("" : "+v"(e.child), "+v"(e.dist)); }
+      else { e = stack[i * stride]; asm volatile("" : "+v"(e.child), "+v"(e.dist)); }
+      return e;
    };
    auto stack_put = [&](int i, StackEntry e) {
-      if (SPILL && i >= RT_LDS_STACK) spill[(size_t)(i - RT_LDS_STACK) * spill_stride] = e;
+      if (SPILL && i >= RT_LDS_STACK) { asm volatile("" : "+v"(e.child), "+v"(e.dist)); spill[(size_t)(i - RT_LDS_STACK) * spill_stride] = e; }
       else stack[i * stride] = e;
    };
    const unsigned lane = __lane_id();
@@ -560,8 +568,14 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    auto finish = [&](bool early) {
       if (COUNT) { max_ray_steps = ray_steps > max_ray_steps ? ray_steps : max_ray_steps; }
       if (!early) plane_scan(sc, c.r, t, closest);
+      if (OUT == OUT_CHAIN && mode == (MODE_SHADOW | MODE_FILTER) && t < toBeat) {
+         /* A feeler the filter found nothing for, but with a plane in front of its target: whether that plane counts
+          * depends, within EPSILON, on what the reference's walk leaves in t, so that walk is made after all. */
+         mode = MODE_SHADOW; cur = sc.root; sp = 0; t = FLT_MAX; closest = -1;
+         return;
+      }
       active = false; cur = RT_CUR_IDLE;
-      if (OUT == OUT_CHAIN && mode != MODE_EXTEND) {
+      if (OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND) {
          /* kernel.cu:206; a feeler that is not shadowed leaves its bit as the launch found it: clear */
          if (less_than(t, toBeat)) atomicOr(a.flag_words + (size_t)idx * a.flag_stride + ((unsigned)tag >> 5), 1u << ((unsigned)tag & 31u));
       } else {
@@ -613,14 +627,21 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       int4 tail = *reinterpret_cast<const int4 *>(rec + 48);
       int2 ch; ch.x = tail.x; ch.y = tail.y;
       StackEntry top = peek();
-      if (COUNT) { if (OUT == OUT_CHAIN && mode != MODE_EXTEND) nvs++; else nv++; }
+      if (COUNT) { if (OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND) nvs++; else nv++; }
       float left, right;
       if (VARIANT == 2) {
          left = slab_literal(c.r, na.x, na.y, na.z, na.w, nb.x, nb.y);
          right = slab_literal(c.r, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w);
       } else {
-         left = slab_fast<VARIANT == 1>(c, na.x, na.y, na.z, na.w, nb.x, nb.y);
-         right = slab_fast<VARIANT == 1>(c, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w);
+         SlabAB sl = slab_ab<VARIANT == 1>(c, na.x, na.y, na.z, na.w, nb.x, nb.y);
+         SlabAB sr = slab_ab<VARIANT == 1>(c, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w);
+         left = slab_value(sl); right = slab_value(sr);
+         if (sc.filter_root != RT_ROOT_EMPTY) {
+            /* a ray still in the miss filter's tree asks the filter's question of the same two numbers */
+            const bool filtering = (mode & MODE_FILTER) != 0;
+            float fl = slab_filter_value(sl), fr = slab_filter_value(sr);
+            left = filtering ? fl : left; right = filtering ? fr : right;
+         }
       }
       /* kernel.cu:148-158 as predicates.  A child that is not ahead (box value not above zero) gets distance
        * +inf; then "right first on `<=`" is r <= l, "closer than the hit so far" is < t (t is finite or
@@ -711,6 +732,17 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
    };
 
+   /* A ray starts its walk.  With a miss filter it first walks the filter's tree (never pruned by t: t stays FLT_MAX)
+    * looking for any primitive it meets at a parameter the reference would accept -- for a feeler: one that could make it
+    * shadowed, i.e. closer than its target by more than EPSILON.  None: the reference's walk would end as it began (no
+    * hit; for a feeler, nothing in front of the target), so the ray is finished as if that walk had been made.  One: the
+    * ray leaves the filter and makes the reference's walk from the root, unchanged.  Rays outside the short box test's
+    * range do not use the filter. */
+   auto enter_tree = [&]() {
+      if (sc.filter_root != RT_ROOT_EMPTY && c.fast) { cur = sc.filter_root; mode |= MODE_FILTER; }
+      else cur = sc.root;
+   };
+
    /* Every wave reaches its exit in a bounded number of steps: a ray visits each node at most once per
     * stack entry, so RT_STEP_CAP is far beyond any real traversal; hitting it means a corrupted scene and
     * is reported through stats[ST_ABORTED] instead of spinning. */
@@ -773,7 +805,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                   float param = plane_intersect(sc, hprim - sc.n_prims, feeler);   /* kernel.cu:351 */
                   if (param == -1.0f) n_skipped++;          /* lit, whatever the walk would find: its bit stays clear */
                   else {
-                     toBeat = param; mode = MODE_SHADOW; cur = sc.root; active = true;
+                     toBeat = param; mode = MODE_SHADOW; enter_tree(); active = true;
                      if (cur == RT_ROOT_EMPTY) finish(false);
                   }
                } else {
@@ -818,7 +850,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                      c = make_ctx(r);
                      if (!sc.fast_ok) c.fast = false;
                      toBeat = q.to_beat; idx = (unsigned)my; tag = q.valid; mode = MODE_EXTEND;
-                     t = FLT_MAX; closest = -1; sp = 0; cur = sc.root;
+                     t = FLT_MAX; closest = -1; sp = 0; enter_tree();
                      active = true; ray_steps = 0; born = (unsigned)guard;
                      if (cur == RT_ROOT_EMPTY) finish(false);
                   }
@@ -850,6 +882,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          for (int burst = 0; burst < a.node_burst; burst++) {
             bool in_node = cur >= 0;                 /* idle lanes hold RT_CUR_IDLE */
             if (__ballot(in_node) == 0) break;
+            /* enough lanes wait at a leaf: their step is worth its price now */
+            if ((int)__popcll(__ballot(cur < 0 && cur != RT_CUR_IDLE)) >= a.leaf_trigger) break;
             if (COUNT) {
                wn++; if (active) ray_steps++;
                if (cur < 0) { if (cur == RT_CUR_IDLE) n_noray++; else n_leafwait++; }
@@ -873,19 +907,26 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          if (at_leaf) {
             top = peek();
             float dist = prim_intersect(sc, ~cur, c.r);
-            if (OUT == OUT_CHAIN && mode == MODE_SETUP) {
+            if (mode & MODE_FILTER) {
+               /* still in the filter's tree: does the ray meet this primitive where it could matter? */
+               bool shadow = OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND;
+               if (COUNT) { if (shadow) nps++; else np++; }
+               const bool matters = above_zero(dist) && (!shadow || less_than(dist, toBeat));
+               if (matters) { mode &= MODE_KIND; cur = sc.root; sp = 0; }      /* the reference's walk, from its root */
+               else tested = true;                                             /* take stays false: on to the next deferred box */
+            } else if (OUT == OUT_CHAIN && mode == MODE_SETUP) {
                /* the feeler against its own surface (kernel.cu:351).  A feeler that misses it (-1) can never be
                 * reported shadowed: isFloatLessThan(closest, -1) is false for every accepted t.  The reference
                 * still walks the tree for it; that walk is skipped here and counted separately. */
                if (dist == -1.0f) { n_skipped++; active = false; cur = RT_CUR_IDLE; }
                else {
-                  toBeat = dist; mode = MODE_SHADOW; cur = sc.root;
+                  toBeat = dist; mode = MODE_SHADOW; enter_tree();
                   if (cur == RT_ROOT_EMPTY) finish(false);
                }
             } else {
                /* what the test does to the traversal state, kernel.cu:104-134; a near-tie with the hit so far is
                 * only marked here and decided below */
-               bool shadow = OUT == OUT_CHAIN && mode != MODE_EXTEND;
+               bool shadow = OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND;
                if (COUNT) { if (shadow) nps++; else np++; }
                if (is_equal(t, dist)) {
                   if (COUNT) { if (shadow) nts++; else nt++; }
@@ -1294,7 +1335,7 @@ struct rt_scene {
    std::vector<int32_t> prim_ids_host;      /* host copy of DScene::prim_ids */
    /* launch shape and tuning of the traversal kernel, read once per scene from its device and the environment */
    int trace_blocks;        /* workgroups of a full traversal launch: what the device holds at 4 waves per SIMD */
-   int refill_idle, node_burst, use_tile_order, order_classes;
+   int refill_idle, node_burst, leaf_trigger, use_tile_order, order_classes;
    double order_mean_weight;
    unsigned reserve;        /* queue entries a wave reserves at a time for its bounce rays */
 };
@@ -1351,6 +1392,8 @@ extern "C" void rt_scene_destroy(rt_scene *s)
 }
 
 static void scene_tuning(rt_scene *s);
+static int env_int(const char *name, int fallback, bool allow_zero);
+static int stack_depth(const rt_scene *s);
 static int scratch_address(int device, char **out);
 
 extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
@@ -1394,6 +1437,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    scene_tuning(s);
    { char *unused = nullptr; (void)scratch_address(device, &unused); }   /* this device's static working memory (rt_trace_rays_static), looked up while the device is current; a failure is reported by that call */
 
+   if (!env_int("RT_MISS_FILTER", 1, true)) flags |= RT_SCENE_NO_FILTER;      /* for A/B runs; frames are the same either way */
    auto t0 = std::chrono::steady_clock::now();
    int st = rt_flatten_scene_ex(desc, flags, &s->host);
    if (st != RT_OK) { delete s; return st; }
@@ -1426,16 +1470,23 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    for (size_t k = 0; k < np_; k++) { if (!perm_ok) pos_of[k] = (int32_t)k; ids[k] = perm_ok ? h.leaf_order[k] : (int32_t)k; }
    std::vector<rt_dev_prim> d_prims(np_); std::vector<rt_dev_xform> d_xforms(np_); std::vector<rt_dev_shade> d_shades(np_);
    for (size_t k = 0; k < np_; k++) { d_prims[k] = h.prims[ids[k]]; d_xforms[k] = h.xforms[ids[k]]; d_shades[k] = h.shades[ids[k]]; }
-   std::vector<rt_bvh_node> d_nodes((size_t)(h.n_nodes > 0 ? h.n_nodes : 0));
+   /* one node array: the tree the rays are answered from, then (if the scene has one) the miss filter's tree, its
+    * internal child references moved behind the first tree's records */
+   const size_t n_tree = (size_t)(h.n_nodes > 0 ? h.n_nodes : 0), n_filter = (size_t)(h.n_filter_nodes > 0 ? h.n_filter_nodes : 0);
+   std::vector<rt_bvh_node> d_nodes(n_tree + n_filter);
    for (size_t k = 0; k < d_nodes.size(); k++) {
-      d_nodes[k] = h.nodes[k];
-      if (d_nodes[k].left < 0) d_nodes[k].left = ~pos_of[(size_t)~d_nodes[k].left];
-      if (d_nodes[k].right < 0) d_nodes[k].right = ~pos_of[(size_t)~d_nodes[k].right];
+      const bool in_filter = k >= n_tree;
+      d_nodes[k] = in_filter ? h.filter_nodes[k - n_tree] : h.nodes[k];
+      int32_t *child[2] = {&d_nodes[k].left, &d_nodes[k].right};
+      for (int c = 0; c < 2; c++) {
+         if (*child[c] < 0) *child[c] = ~pos_of[(size_t)~*child[c]];
+         else if (in_filter) *child[c] += (int32_t)n_tree;
+      }
    }
    s->prim_ids_host = ids;
    enum { N_ARR = 10 };
    size_t off[N_ARR + 1], sizes[N_ARR] = {
-      sizeof(rt_bvh_node) * (size_t)h.n_nodes, sizeof(rt_dev_prim) * (size_t)h.n_prims,
+      sizeof(rt_bvh_node) * d_nodes.size(), sizeof(rt_dev_prim) * (size_t)h.n_prims,
       sizeof(rt_dev_xform) * (size_t)h.n_prims, sizeof(rt_dev_shade) * (size_t)h.n_prims,
       sizeof(rt_dev_plane) * (size_t)h.n_planes, sizeof(rt_material) * (size_t)h.n_materials,
       sizeof(rt_dev_light) * (size_t)h.n_lights, sizeof(rt_dev_texinfo) * (size_t)h.n_textures, 4 * h.n_texels,
@@ -1462,6 +1513,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->d.n_prims = h.n_prims; s->d.n_planes = h.n_planes; s->d.n_lights = h.n_lights;
    s->d.root = (h.root < 0 && h.root != RT_ROOT_EMPTY) ? ~pos_of[(size_t)~h.root] : h.root;
    s->d.fast_ok = h.bounds_in_range;
+   s->d.filter_root = (n_filter > 0 && h.root >= 0) ? (int)n_tree : RT_ROOT_EMPTY;
    s->d.any_xform = h.any_xform;
 
    if (hipMalloc((void **)&s->d_ctr, RT_CTR_WORDS * sizeof(unsigned long long)) != hipSuccess ||
@@ -1469,8 +1521,8 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
        hipHostMalloc((void **)&s->h_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
       rt_set_error("allocation of queue counters failed"); rt_scene_destroy(s); return RT_ERR_HIP;
    }
-   if (h.tree_depth > RT_LDS_STACK) {
-      const size_t bytes = sizeof(StackEntry) * (size_t)(h.tree_depth - RT_LDS_STACK) * (size_t)s->trace_blocks * RT_BLOCK;
+   if (stack_depth(s) > RT_LDS_STACK) {
+      const size_t bytes = sizeof(StackEntry) * (size_t)(stack_depth(s) - RT_LDS_STACK) * (size_t)s->trace_blocks * RT_BLOCK;
       if (hipMalloc((void **)&s->d_spill, bytes) != hipSuccess) { rt_set_error("allocation of %zu bytes of traversal stack failed", bytes); rt_scene_destroy(s); return RT_ERR_HIP; }
    }
    {
@@ -1495,6 +1547,7 @@ extern "C" int rt_scene_get_info(const rt_scene *s, rt_scene_info *info)
    info->n_nodes = s->host.n_nodes; info->n_materials = s->host.n_materials; info->tree_depth = s->host.tree_depth;
    info->root = s->host.root; info->device_bytes = s->dev_bytes;
    info->ms_build_host = s->ms_build_host; info->ms_upload = s->ms_upload; info->ms_build_device = s->ms_build_device;
+   info->filter_depth = s->host.n_filter_nodes > 0 ? s->host.filter_depth : 0;
    return RT_OK;
 }
 
@@ -1599,16 +1652,23 @@ static long long max_batch_slots()
    return v > 0 ? v : (long long)(1 << 26);
 }
 
+/* entries the deepest walk can defer: one per internal level of the deeper of the scene's trees */
+static int stack_depth(const rt_scene *s)
+{
+   int depth = s->host.tree_depth > s->host.filter_depth ? s->host.tree_depth : s->host.filter_depth;
+   return depth > 0 ? depth : 1;
+}
+
 static int trace_lds_bytes(const rt_scene *s, size_t *out)
 {
    /* the stack holds at most one deferred sibling per internal level; RT_LDS_STACK of them live in LDS */
-   int depth = s->host.tree_depth > 0 ? s->host.tree_depth : 1;
+   int depth = stack_depth(s);
    if (depth > RT_LDS_STACK) depth = RT_LDS_STACK;
    *out = sizeof(StackEntry) * (size_t)RT_BLOCK * (size_t)depth;
    return RT_OK;
 }
 
-static int env_int(const char *name, int fallback, bool allow_zero = false)
+static int env_int(const char *name, int fallback, bool allow_zero)
 {
    const char *e = getenv(name);
    if (!e) return fallback;
@@ -1623,13 +1683,14 @@ static void scene_tuning(rt_scene *s)
    int cus = 256;
    hipDeviceProp_t prop;
    if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-   s->trace_blocks = env_int("RT_TRACE_BLOCKS", cus * 4);
-   s->refill_idle = env_int("RT_REFILL_IDLE", RT_REFILL_IDLE);
-   s->node_burst = env_int("RT_NODE_BURST", RT_NODE_BURST);
+   s->trace_blocks = env_int("RT_TRACE_BLOCKS", cus * 4, false);
+   s->refill_idle = env_int("RT_REFILL_IDLE", RT_REFILL_IDLE, false);
+   s->node_burst = env_int("RT_NODE_BURST", RT_NODE_BURST, false);
+   s->leaf_trigger = env_int("RT_LEAF_TRIGGER", RT_LEAF_TRIGGER, false);
    s->use_tile_order = env_int("RT_TILE_ORDER", 1, true);
-   s->order_classes = env_int("RT_ORDER_CLASSES", RT_ORDER_CLASSES);
+   s->order_classes = env_int("RT_ORDER_CLASSES", RT_ORDER_CLASSES, false);
    s->order_mean_weight = (double)env_int("RT_ORDER_MEAN_WEIGHT", RT_ORDER_MEAN_WEIGHT, true);
-   int r = env_int("RT_RESERVE", RT_RESERVE);
+   int r = env_int("RT_RESERVE", RT_RESERVE, false);
    s->reserve = (unsigned)(r < 128 ? 128 : r);      /* one spawn stage can ask for 128 entries */
 }
 
@@ -1651,11 +1712,11 @@ static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs 
    unsigned long long want = (n_hint + RT_BLOCK - 1) / RT_BLOCK;
    unsigned blocks = (unsigned)(want < (unsigned long long)s->trace_blocks ? want : (unsigned long long)s->trace_blocks);
    if (blocks == 0) return;
-   a.refill_idle = s->refill_idle; a.node_burst = s->node_burst;
+   a.refill_idle = s->refill_idle; a.node_burst = s->node_burst; a.leaf_trigger = s->leaf_trigger;
    a.reserve = s->reserve;
    if (!a.stats) a.stats = s->d_stats;
    a.spill = s->d_spill;
-   const bool spill = s->host.tree_depth > RT_LDS_STACK;
+   const bool spill = stack_depth(s) > RT_LDS_STACK;
 #define RT_LAUNCH_TRACE(O, C) do { if (spill) hipLaunchKernelGGL((k_trace<O, C, true>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, a); \
                                    else hipLaunchKernelGGL((k_trace<O, C, false>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, a); } while (0)
    if (out_mode == OUT_CHAIN) { if (count) RT_LAUNCH_TRACE(OUT_CHAIN, true); else RT_LAUNCH_TRACE(OUT_CHAIN, false); }

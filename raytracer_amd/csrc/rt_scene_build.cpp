@@ -515,6 +515,41 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
       }
    }
 
+   /* The miss filter: beside the reference's tree, a surface-area tree over the same primitive boxes, every box
+    * widened a little.  It decides nothing the reference decides; the traversal kernel only uses it to prove that a ray
+    * meets no primitive at all (then the reference's walk would come back empty-handed too, whatever its order), and
+    * walks the reference's tree for every ray it cannot prove that for.  Built only beside the reference's tree. */
+   std::vector<rt_bvh_node> filter;
+   int filter_depth = 0;
+   int filter_min = RT_FILTER_MIN_PRIMS;
+   if (const char *e = getenv("RT_FILTER_MIN_PRIMS")) { if (atoi(e) >= 2) filter_min = atoi(e); }     /* tests lower it to put small scenes through the filter */
+   if (n >= filter_min && !(flags & (RT_SCENE_FAST_BVH | RT_SCENE_GPU_BVH | RT_SCENE_NO_FILTER))) {
+      std::vector<int32_t> ids((size_t)n);
+      for (int i = 0; i < n; i++) ids[(size_t)i] = i;
+      std::vector<TreeNode> pool;
+      pool.reserve((size_t)(2 * n));
+      int levels = 0; while ((1 << levels) < n) levels++;
+      SahBuilder sb{b.boxes, ids, pool};
+      /* no deeper than the traversal stack's share of LDS where the primitive count allows that: a filter that pushed
+       * the stack into global memory would cost more than its better splits win */
+      int budget = levels + 2 > RT_FILTER_DEPTH ? levels + 2 : RT_FILTER_DEPTH;
+      int root_node = sb.build(0, n, budget);
+      if (pool[(size_t)root_node].prim < 0) {
+         flatten_tree(pool, root_node, filter, &filter_depth);
+         /* Every box of this tree contains the reference's own (padded) boxes of the primitives below it.  It is
+          * widened by 1e-4 plus a few units in the last place of its coordinates, far more than the rounding of the
+          * box test, so that a ray the reference's test lets into a primitive's own box is never turned away here. */
+         for (size_t k = 0; k < filter.size(); k++) {
+            float *v = filter[k].lmin;      /* lmin, lmax, rmin, rmax */
+            for (int j = 0; j < 12; j++) {
+               const float pad = 1e-4f + 8e-6f * std::fabs(v[j]);
+               const bool is_max = (j / 3) & 1;
+               v[j] = is_max ? v[j] + pad : v[j] - pad;
+            }
+         }
+      }
+   }
+
    std::vector<rt_dev_light> lights((size_t)d->n_lights);
    for (int i = 0; i < d->n_lights; i++) {
       memset(&lights[(size_t)i], 0, sizeof(rt_dev_light));
@@ -531,6 +566,13 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
       for (int j = 0; j < 12; j++)
          if (!(std::fabs(v[j]) <= 1.099511627776e12f)) out->bounds_in_range = 0;
    }
+   for (size_t k = 0; k < filter.size(); k++) {
+      const float *v = filter[k].lmin;
+      for (int j = 0; j < 12; j++)
+         if (!(std::fabs(v[j]) <= 1.099511627776e12f)) { filter.clear(); filter_depth = 0; break; }    /* out of the box test's range: no filter */
+   }
+   out->n_filter_nodes = (int32_t)filter.size(); out->filter_depth = filter_depth;
+   out->filter_nodes = copy_out(filter);
    out->nodes = copy_out(flat);
    out->prims = copy_out(b.prims);
    out->xforms = copy_out(b.xforms);
@@ -567,7 +609,7 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
 extern "C" void rt_flat_scene_free(rt_flat_scene *fs)
 {
    if (!fs) return;
-   free(fs->nodes); free(fs->prims); free(fs->xforms); free(fs->shades); free(fs->planes);
+   free(fs->nodes); free(fs->filter_nodes); free(fs->prims); free(fs->xforms); free(fs->shades); free(fs->planes);
    free(fs->materials); free(fs->lights); free(fs->leaf_order); free(fs->tex_info); free(fs->texels); free(fs->prim_boxes);
    memset(fs, 0, sizeof *fs);
 }

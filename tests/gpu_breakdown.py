@@ -29,6 +29,8 @@ def run(name):
             if i >= 2 and (best is None or st["ms_total"] < best["ms_total"]):
                 best = st
     with ra.Scene(sd, counters=True) as sc:
+        info = sc.info()
+        print(f"   tree depth {info['tree_depth']}, filter depth {info['filter_depth']}", flush=True)
         for i in range(2):
             _, ct = sc.render(w, h, spp, shading, abi.RT_JITTER_HASH)
     st = best
