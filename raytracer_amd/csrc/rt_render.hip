@@ -728,8 +728,6 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       }
       if (pend) *reinterpret_cast<float4 *>(a.recs + idx) = make_float4(out.refl, out.alpha, __int_as_float(out.child_refl), __int_as_float(out.child_refr));
       pend = false;
-      /* the rays just stored are read back by this wave only; make the stores complete before that */
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
    };
 
    /* A ray starts its walk.  With a miss filter it first walks the filter's tree (never pruned by t: t stays FLT_MAX)
@@ -753,36 +751,44 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       bool any_pend = OUT == OUT_CHAIN && __ballot(pend) != 0;
       if ((n_idle >= a.refill_idle || m_active == 0) && (!exhausted || list_count > 0 || any_pend)) {
          const unsigned long long clk0 = COUNT ? wall_clock64() : 0ULL;
-         if (any_pend) spawn_stage();
          if (COUNT) n_refills++;
+         /* What this wave stored in earlier refills (list entries, queue entries, shaded points) is read back below, by
+          * other lanes of the wave: those stores are complete first.  They were issued at least a burst of node steps
+          * ago, so this costs nothing; a fence behind the stores themselves cost a memory round trip per refill. */
+         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
          unsigned long long m_idle = ~m_active;
          int rank = __popcll(m_idle & below);
          int take = 0;
          if (OUT == OUT_CHAIN) take = n_idle < list_count ? n_idle : list_count;
          int need = exhausted ? 0 : n_idle - take;
-         /* Primaries for the idle lanes that get no list entry.  The sample slots are dealt out in patches of 64 to
-          * RT_FETCH_STREAMS streams (patch p belongs to stream p mod RT_FETCH_STREAMS), each with a counter of its own:
-          * the waves of a launch spread over the streams, so that no counter is asked more often than it can answer,
-          * and a wave whose stream has run dry moves on to the next one until it has seen them all dry.  The streams
-          * advance together, so the slots are still started in (nearly) their order. */
+         /* The fetches that say what the idle lanes get are issued first and awaited last, behind the spawn stage's own
+          * fetches: the list entries (the oldest go first: with newest first an old entry waits for as long as newer ones
+          * keep arriving, and the subtree behind it starts only when the queue has run dry and stretches the end of the
+          * launch), and the counter for the lanes that get no list entry.
+          * The sample slots are dealt out in patches of 64 to RT_FETCH_STREAMS streams (patch p belongs to stream
+          * p mod RT_FETCH_STREAMS), each with a counter of its own: the waves of a launch spread over the streams, so that
+          * no counter is asked more often than it can answer, and a wave whose stream has run dry moves on to the next one
+          * until it has seen them all dry.  The streams advance together, so the slots are still started in (nearly)
+          * their order. */
+         unsigned long long q_raw = 0;
+         if (need > 0 && lane == 0) q_raw = atomicAdd(a.next + (size_t)stream * 8, (unsigned long long)need);
+         uint2 item = make_uint2(0u, 0u);
+         const bool own = !active && rank < take;
+         if (own) item = list_get(rank);
+         list_head = (list_head + take) & list_mask;
+         list_count -= take;
+         /* what the lanes that finished since the last refill spawn goes behind the entries that stay on the list */
+         if (any_pend) spawn_stage();
          unsigned long long q_base = 0, q_len = 0;
          const unsigned my_stream = stream;
          if (need > 0) {
-            if (lane == 0) q_base = atomicAdd(a.next + (size_t)stream * 8, (unsigned long long)need);
-            q_base = __shfl(q_base, 0);
+            q_base = __shfl(q_raw, 0);
             q_len = n_patches > stream ? ((n_patches - stream + RT_FETCH_STREAMS - 1) / RT_FETCH_STREAMS) * 64ULL : 0ULL;
             if (q_base + (unsigned long long)need >= q_len) {
                stream = stream + 1 == RT_FETCH_STREAMS ? 0u : stream + 1;
                if (++streams_dry == RT_FETCH_STREAMS) exhausted = true;
             }
          }
-         uint2 item = make_uint2(0u, 0u);
-         const bool own = !active && rank < take;
-         /* The oldest entries go first: with newest first an old entry waits for as long as newer ones keep arriving,
-          * and the subtree behind it starts only when the queue has run dry and stretches the end of the launch. */
-         if (own) item = list_get(rank);
-         list_head = (list_head + take) & list_mask;
-         list_count -= take;
          bool put_back = false;
          if (!active) {
             if (OUT == OUT_CHAIN && own && (item.x & RT_SHADOW_ITEM)) {
@@ -863,7 +869,6 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                /* at most as many go back as were taken, so there is room */
                if (put_back) list_put(list_count + __popcll(mP & below), item);
                list_count += __popcll(mP);
-               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             }
          }
          m_active = __ballot(active);
