@@ -58,6 +58,7 @@ struct DScene {
    const rt_dev_texinfo *tex_info;
    const uchar4 *texels;
    const int *prim_ids;     /* primitive id (the caller's numbering) of device primitive k; see rt_scene_create */
+   const int *leaf_parent;  /* scenes with a miss filter: the node of the reference's tree whose child device primitive k is */
    int n_prims, n_planes, n_lights, root;
    int filter_root;  /* node index of the miss filter's root, or RT_ROOT_EMPTY when the scene has none */
    int fast_ok;      /* every BVH bound is finite and below 2^40 in magnitude */
@@ -366,7 +367,14 @@ __device__ __forceinline__ Ray camera_ray(const DCamera &cam, const DGrid &g, in
  *            own: primaries dry, list empty, lanes idle. */
 enum { OUT_HIT = 0, OUT_CHAIN = 2 };
 enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2, MODE_KIND = 3,
-       MODE_FILTER = 4 };   /* set while the ray is still in the miss filter's tree (see enter_tree below) */
+       MODE_FILTER = 4,     /* set while the ray is still in the second tree (see enter_tree below) */
+       MODE_VERIFY = 8 };   /* set while the ray walks the reference's tree from the root down to one leaf */
+/* How far beyond the nearest hit so far a closest-hit ray still looks in the second tree: every box that starts
+ * within RT_LOOK_ABS + t * RT_LOOK_REL behind it.  It has to know of every primitive within EQUAL_EPSILON of its
+ * nearest one; the rest of the margin is allowance for a primitive's computed parameter lying in front of where its
+ * (widened) box starts, which rounding in the primitive test could cause. */
+#define RT_LOOK_ABS 0.05f
+#define RT_LOOK_REL 0.0078125f
 #define RT_SHADOW_ITEM 0x80000000u
 
 #define RT_STEP_CAP (1ULL << 28)
@@ -566,6 +574,17 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
 
    /* a ray is finished: scan the planes unless it left early, write its result */
    auto finish = [&](bool early) {
+      if (OUT == OUT_CHAIN && mode == (MODE_EXTEND | MODE_FILTER) && closest >= 0) {
+         /* The second tree has been searched: `closest` at t is the nearest primitive the ray meets, toBeat the nearest
+          * of all the others.  If those are more than EQUAL_EPSILON apart (and t is clear of the parameters of
+          * primitives behind the origin), the reference's walk reports this primitive whatever its order -- nothing else
+          * can tie with it or beat it -- provided it reaches the leaf at all; that is checked on the reference's tree,
+          * along the one path from its root to that leaf.  Otherwise the reference's walk is made in full. */
+         const bool alone = t > 2.0f * RT_EQ_EPS && !(t + RT_EQ_EPS > toBeat);
+         if (alone) { mode = MODE_EXTEND | MODE_VERIFY; toBeat = __int_as_float(sc.leaf_parent[closest]); cur = sc.root; }
+         else { mode = MODE_EXTEND; toBeat = -FLT_MAX; t = FLT_MAX; closest = -1; cur = sc.root; sp = 0; }
+         return;
+      }
       if (COUNT) { max_ray_steps = ray_steps > max_ray_steps ? ray_steps : max_ray_steps; }
       if (!early) plane_scan(sc, c.r, t, closest);
       if (OUT == OUT_CHAIN && mode == (MODE_SHADOW | MODE_FILTER) && t < toBeat) {
@@ -595,21 +614,28 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       asm volatile("" : "+v"(e.child), "+v"(e.dist));      /* one 64-bit read, issued here */
       return e;
    };
-   /* pop deferred siblings until one is still closer than t (kernel.cu:160-186); none left = done */
-   auto pop = [&](StackEntry top) {
+   /* Boxes at or beyond this are not entered.  The reference's walk: t.  A closest-hit ray in the second tree looks a
+    * little further than its nearest hit so far (RT_LOOK_*); a feeler there carries its limit in t already. */
+   auto look_cut = [&]() {
+      const bool widen = OUT == OUT_CHAIN && mode == (MODE_EXTEND | MODE_FILTER);
+      return widen ? __builtin_fmaf(t, 1.0f + RT_LOOK_REL, RT_LOOK_ABS) : t;
+   };
+   /* pop deferred siblings until one is still closer than t (kernel.cu:160-186); none left = done.  `cut` is t, or
+    * what stands in for it while the ray is in the second tree (see look_cut). */
+   auto pop = [&](StackEntry top, float cut) {
       /* the first try uses the entry read ahead (nearly always enough: an entry goes stale only when t has shrunk
        * since it was pushed); the loop behind it walks past stale entries */
       bool found = false;
       if (sp > 0) {
          sp--;
-         found = top.dist < t;
+         found = top.dist < cut;
          if (found) cur = top.child;
       }
       if (!found) {
          while (sp > 0) {
             sp--;
             StackEntry e = stack_get(sp);
-            if (e.dist < t) { cur = e.child; found = true; break; }
+            if (e.dist < cut) { cur = e.child; found = true; break; }
          }
          if (!found) finish(false);
       }
@@ -649,19 +675,57 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       asm volatile("" : : "v"(tail.z), "v"(tail.w));
       const float inf = __builtin_inff();
       float l = above_zero(left) ? left : inf, r = above_zero(right) ? right : inf;
-      bool goR = r <= l && r < t;
-      bool goL = !goR && l < t;
+      const float cut = look_cut();
+      bool goR = r <= l && r < cut;
+      bool goL = !goR && l < cut;
       float other = goR ? l : r;
+      if (OUT == OUT_CHAIN && sc.filter_root != RT_ROOT_EMPTY) {
+         /* A ray on its way down to the leaf of `closest` (the leaf hangs below node toBeat; nodes are numbered parent,
+          * left subtree, right subtree) takes the turn towards it and defers nothing.  The reference's walk takes the
+          * same turn here -- at once, or later from its stack -- if the child's box is ahead and starts in front of every
+          * t the walk can hold before it reaches that leaf, and the least of those is beyond t + EQUAL_EPSILON
+          * (kernel.cu:139-175).  If not, nothing is known: the reference's walk is made in full. */
+         if (mode & MODE_VERIFY) {
+            const int hangs_at = __float_as_int(toBeat);
+            const bool right_turn = ch.y >= 0 ? hangs_at >= ch.y : ~ch.y == closest;
+            if ((right_turn ? r : l) < t + RT_EQ_EPS) cur = right_turn ? ch.y : ch.x;      /* at the leaf: the leaf step ends the ray */
+            else { mode = MODE_EXTEND; toBeat = -FLT_MAX; t = FLT_MAX; closest = -1; cur = sc.root; sp = 0; }
+            return;
+         }
+      }
       if ((goR || goL) && other < inf) {
          StackEntry e; e.child = goR ? ch.x : ch.y; e.dist = other;
          stack_put(sp, e); sp++;
       }
       if (goR || goL) cur = goR ? ch.y : ch.x;
-      else pop(top);
+      else pop(top, cut);
    };
+   /* A ray starts its walk.  With a miss filter it first walks the filter's tree (never pruned by t: t stays FLT_MAX)
+    * looking for any primitive it meets at a parameter the reference would accept -- for a feeler: one that could make it
+    * shadowed, i.e. closer than its target by more than EPSILON.  None: the reference's walk would end as it began (no
+    * hit; for a feeler, nothing in front of the target), so the ray is finished as if that walk had been made.  One: the
+    * ray leaves the filter and makes the reference's walk from the root, unchanged.  Rays outside the short box test's
+    * range do not use the filter. */
+   auto enter_tree = [&]() {
+      if (sc.filter_root != RT_ROOT_EMPTY && c.fast && !wave_lit) {
+         cur = sc.filter_root; mode |= MODE_FILTER;
+         if (OUT == OUT_CHAIN) {
+            if ((mode & MODE_KIND) == MODE_EXTEND) toBeat = FLT_MAX;      /* the nearest of the other primitives, so far */
+            else t = toBeat * (1.0f + 1.0f / 1024.0f);                    /* nothing that starts behind the target can shadow it */
+         }
+      } else cur = sc.root;
+   };
+   /* out of the second tree with nothing learnt: the reference's walk from its root */
+   auto leave_filter = [&]() {
+      if (OUT == OUT_CHAIN && (mode & MODE_KIND) == MODE_EXTEND) toBeat = -FLT_MAX;
+      mode &= MODE_KIND; t = FLT_MAX; closest = -1; cur = sc.root; sp = 0;
+   };
+
    /* OUT_CHAIN: every lane that finished since the last call writes its spawn record and appends its bounce rays */
    auto spawn_stage = [&]() {
       bool want_refl = false, want_refr = false, shaded = false;
+      bool cont_refl = false, cont_refr = false;      /* this lane goes on with its reflection / refraction ray itself */
+      bool front_pushed = false;                      /* wave-uniform: entries were put at the front of the list */
       BounceRays b;
       SpawnRec out;
       out.refl = out.alpha = 0.0f; out.child_refl = out.child_refr = -1;
@@ -708,37 +772,50 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             unsigned long long oR = __ballot(okR), oT = __ballot(okT);
             unsigned nR = __popcll(oR), nT = __popcll(oT);
             res_lo += cnt < res_hi - res_lo ? cnt : res_hi - res_lo;
-            /* in list order: the refraction rays, the reflection rays, the shadow items */
             if (okT) {
                store_qray(a.rays, slotT, mk3(b.to[0], b.to[1], b.to[2]), mk3(b.td[0], b.td[1], b.td[2]), -FLT_MAX, tag + 1);
                out.child_refr = (int)slotT;
-               list_put(list_count + __popcll(oT & below), make_uint2(slotT, 0u));
             }
             if (okR) {
                store_qray(a.rays, slotR, mk3(b.ro[0], b.ro[1], b.ro[2]), mk3(b.rd[0], b.rd[1], b.rd[2]), -FLT_MAX, tag + 1);
                out.child_refl = (int)slotR;
-               list_put(list_count + nT + __popcll(oR & below), make_uint2(slotR, 0u));
             }
-            if (want_sh) list_put(list_count + nT + nR + __popcll(mS & below), make_uint2(RT_SHADOW_ITEM | idx, 0u));   /* light 0 of entry idx */
-            list_count += (int)(nR + nT + cS);
+            /* The shadow items go to the back of the list.  A lane with a bounce ray traces it itself, at once: the
+             * bounce rays are the launch's longest dependent chains (up to six levels, each waiting for the one
+             * before), and a chain that queued behind the list's backlog at every level would set the length of the
+             * launch.  A lane with two bounce rays keeps the reflection and puts the refraction ray at the front of the
+             * list, ahead of every shadow item, for the same reason. */
+            if (want_sh) list_put(list_count + __popcll(mS & below), make_uint2(RT_SHADOW_ITEM | idx, 0u));   /* light 0 of entry idx */
+            list_count += (int)cS;
+            const bool second = okR && okT;
+            const unsigned long long m2 = __ballot(second);
+            if (m2) {
+               const int n2 = (int)__popcll(m2);
+               list_head = (list_head - n2) & list_mask;
+               if (second) list_put((int)__popcll(m2 & below), make_uint2(slotT, 0u));
+               list_count += n2;
+               front_pushed = true;
+            }
             list_peak = list_count > list_peak ? list_count : list_peak;
             w_refl += cR; w_refr += cT;
             if (nR + nT != cnt && lane == 0) stat_add(stats, ST_OVERFLOW, 1ULL);   /* the queue is full: the host retries with a larger one */
+            cont_refl = okR; cont_refr = okT && !okR;
          }
       }
       if (pend) *reinterpret_cast<float4 *>(a.recs + idx) = make_float4(out.refl, out.alpha, __int_as_float(out.child_refl), __int_as_float(out.child_refr));
       pend = false;
-   };
-
-   /* A ray starts its walk.  With a miss filter it first walks the filter's tree (never pruned by t: t stays FLT_MAX)
-    * looking for any primitive it meets at a parameter the reference would accept -- for a feeler: one that could make it
-    * shadowed, i.e. closer than its target by more than EPSILON.  None: the reference's walk would end as it began (no
-    * hit; for a feeler, nothing in front of the target), so the ray is finished as if that walk had been made.  One: the
-    * ray leaves the filter and makes the reference's walk from the root, unchanged.  Rays outside the short box test's
-    * range do not use the filter. */
-   auto enter_tree = [&]() {
-      if (sc.filter_root != RT_ROOT_EMPTY && c.fast) { cur = sc.filter_root; mode |= MODE_FILTER; }
-      else cur = sc.root;
+      if (cont_refl || cont_refr) {
+         Ray r;
+         r.o = cont_refl ? mk3(b.ro[0], b.ro[1], b.ro[2]) : mk3(b.to[0], b.to[1], b.to[2]);
+         r.d = cont_refl ? mk3(b.rd[0], b.rd[1], b.rd[2]) : mk3(b.td[0], b.td[1], b.td[2]);
+         c = make_ctx(r);
+         if (!sc.fast_ok) c.fast = false;
+         toBeat = -FLT_MAX; idx = (unsigned)(cont_refl ? out.child_refl : out.child_refr); tag = tag + 1; mode = MODE_EXTEND;
+         t = FLT_MAX; closest = -1; sp = 0; enter_tree();
+         active = true; ray_steps = 0; born = (unsigned)guard;
+         if (cur == RT_ROOT_EMPTY) finish(false);
+      }
+      return front_pushed;
    };
 
    /* Every wave reaches its exit in a bounded number of steps: a ray visits each node at most once per
@@ -756,15 +833,22 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
           * other lanes of the wave: those stores are complete first.  They were issued at least a burst of node steps
           * ago, so this costs nothing; a fence behind the stores themselves cost a memory round trip per refill. */
          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+         /* what the lanes that finished since the last refill spawn: a lane with a bounce ray goes on with it, the rest
+          * goes onto the list */
+         if (any_pend) {
+            const bool front = spawn_stage();
+            /* entries put at the front are taken below, by other lanes: their rays have to be in memory first */
+            if (front) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            m_active = __ballot(active);
+            n_idle = 64 - __popcll(m_active);
+         }
          unsigned long long m_idle = ~m_active;
          int rank = __popcll(m_idle & below);
          int take = 0;
          if (OUT == OUT_CHAIN) take = n_idle < list_count ? n_idle : list_count;
          int need = exhausted ? 0 : n_idle - take;
-         /* The fetches that say what the idle lanes get are issued first and awaited last, behind the spawn stage's own
-          * fetches: the list entries (the oldest go first: with newest first an old entry waits for as long as newer ones
-          * keep arriving, and the subtree behind it starts only when the queue has run dry and stretches the end of the
-          * launch), and the counter for the lanes that get no list entry.
+         /* The fetches that say what the idle lanes get: the list entries (from the front: refraction rays first, then
+          * the shadow items, oldest first), and the counter for the lanes that get no list entry.
           * The sample slots are dealt out in patches of 64 to RT_FETCH_STREAMS streams (patch p belongs to stream
           * p mod RT_FETCH_STREAMS), each with a counter of its own: the waves of a launch spread over the streams, so that
           * no counter is asked more often than it can answer, and a wave whose stream has run dry moves on to the next one
@@ -777,8 +861,6 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          if (own) item = list_get(rank);
          list_head = (list_head + take) & list_mask;
          list_count -= take;
-         /* what the lanes that finished since the last refill spawn goes behind the entries that stay on the list */
-         if (any_pend) spawn_stage();
          unsigned long long q_base = 0, q_len = 0;
          const unsigned my_stream = stream;
          if (need > 0) {
@@ -874,6 +956,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          m_active = __ballot(active);
          wave_par = __ballot(active && c.par != 0) != 0;
          wave_lit = __ballot(active && !c.fast) != 0;
+         /* the literal box test has no reading for the second tree's question: a wave that has to use it keeps no ray there */
+         if (wave_lit && active && (mode & MODE_FILTER)) leave_filter();
          if (COUNT) clk_refill += wall_clock64() - clk0;
       }
       if (m_active == 0) {
@@ -911,14 +995,31 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          StackEntry top; top.child = 0; top.dist = 0.0f;
          if (at_leaf) {
             top = peek();
-            float dist = prim_intersect(sc, ~cur, c.r);
-            if (mode & MODE_FILTER) {
+            float dist = 0.0f;
+            if (!(OUT == OUT_CHAIN && (mode & MODE_VERIFY))) dist = prim_intersect(sc, ~cur, c.r);
+            if (OUT == OUT_CHAIN && (mode & MODE_VERIFY)) {
+               /* the way down from the root has arrived: the reference's walk tests this leaf too, so its answer is
+                * `closest` at t; on to the planes (the stack is empty, the pop below ends the ray) */
+               mode = MODE_EXTEND; toBeat = -FLT_MAX; sp = 0;
+               if (~cur == closest) tested = true;
+               else { t = FLT_MAX; closest = -1; cur = sc.root; }       /* not the leaf it set out for: the reference's walk in full */
+            } else if (mode & MODE_FILTER) {
                /* still in the filter's tree: does the ray meet this primitive where it could matter? */
                bool shadow = OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND;
                if (COUNT) { if (shadow) nps++; else np++; }
-               const bool matters = above_zero(dist) && (!shadow || less_than(dist, toBeat));
-               if (matters) { mode &= MODE_KIND; cur = sc.root; sp = 0; }      /* the reference's walk, from its root */
-               else tested = true;                                             /* take stays false: on to the next deferred box */
+               if (OUT == OUT_CHAIN && !shadow) {
+                  /* a closest-hit ray keeps the nearest primitive it meets (t, closest) and the parameter of the
+                   * nearest of the others (toBeat) */
+                  if (above_zero(dist)) {
+                     if (dist < t) { toBeat = t; t = dist; closest = ~cur; }
+                     else toBeat = fminf(toBeat, dist);
+                  }
+                  tested = true;
+               } else {
+                  const bool matters = above_zero(dist) && (!shadow || less_than(dist, toBeat));
+                  if (matters) leave_filter();     /* the reference's walk, from its root */
+                  else tested = true;              /* take stays false: on to the next deferred box */
+               }
             } else if (OUT == OUT_CHAIN && mode == MODE_SETUP) {
                /* the feeler against its own surface (kernel.cu:351).  A feeler that misses it (-1) can never be
                 * reported shadowed: isFloatLessThan(closest, -1) is false for every accepted t.  The reference
@@ -954,7 +1055,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             bool early = false;
             if (take) { t = leaf_dist; closest = ~cur; early = t < toBeat; }      /* kernel.cu:117-121, 128-132 */
             if (early) finish(true);
-            else pop(top);
+            else pop(top, look_cut());
          }
       }
       if (COUNT) clk_leaf += wall_clock64() - clk2;
@@ -1489,20 +1590,27 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
       }
    }
    s->prim_ids_host = ids;
-   enum { N_ARR = 10 };
+   /* where each leaf hangs in the reference's tree, for walking the path from the root down to one leaf */
+   std::vector<int32_t> leaf_parent(n_filter > 0 ? np_ : 0, 0);
+   if (n_filter > 0)
+      for (size_t k = 0; k < n_tree; k++) {
+         if (d_nodes[k].left < 0) leaf_parent[(size_t)~d_nodes[k].left] = (int32_t)k;
+         if (d_nodes[k].right < 0) leaf_parent[(size_t)~d_nodes[k].right] = (int32_t)k;
+      }
+   enum { N_ARR = 11 };
    size_t off[N_ARR + 1], sizes[N_ARR] = {
       sizeof(rt_bvh_node) * d_nodes.size(), sizeof(rt_dev_prim) * (size_t)h.n_prims,
       sizeof(rt_dev_xform) * (size_t)h.n_prims, sizeof(rt_dev_shade) * (size_t)h.n_prims,
       sizeof(rt_dev_plane) * (size_t)h.n_planes, sizeof(rt_material) * (size_t)h.n_materials,
       sizeof(rt_dev_light) * (size_t)h.n_lights, sizeof(rt_dev_texinfo) * (size_t)h.n_textures, 4 * h.n_texels,
-      sizeof(int32_t) * np_};
+      sizeof(int32_t) * np_, sizeof(int32_t) * leaf_parent.size()};
    off[0] = 0;
    for (int k = 0; k < N_ARR; k++) off[k + 1] = off[k] + align_up(sizes[k] ? sizes[k] : 64, 256);
    s->dev_bytes = off[N_ARR];
    hipError_t e = hipMalloc(&s->dev_blob, s->dev_bytes);
    if (e != hipSuccess) { rt_set_error("hipMalloc(%zu) failed: %s", s->dev_bytes, hipGetErrorString(e)); rt_scene_destroy(s); return RT_ERR_HIP; }
    const void *src[N_ARR] = {d_nodes.data(), d_prims.data(), d_xforms.data(), d_shades.data(), h.planes, h.materials, h.lights, h.tex_info,
-                             h.texels, ids.data()};
+                             h.texels, ids.data(), leaf_parent.data()};
    for (int k = 0; k < N_ARR; k++) {
       if (!sizes[k]) continue;
       e = hipMemcpy((char *)s->dev_blob + off[k], src[k], sizes[k], hipMemcpyHostToDevice);
@@ -1514,7 +1622,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->d.planes = (const rt_dev_plane *)(b + off[4]); s->d.materials = (const rt_material *)(b + off[5]);
    s->d.lights = (const rt_dev_light *)(b + off[6]);
    s->d.tex_info = (const rt_dev_texinfo *)(b + off[7]); s->d.texels = (const uchar4 *)(b + off[8]);
-   s->d.prim_ids = (const int *)(b + off[9]);
+   s->d.prim_ids = (const int *)(b + off[9]); s->d.leaf_parent = (const int *)(b + off[10]);
    s->d.n_prims = h.n_prims; s->d.n_planes = h.n_planes; s->d.n_lights = h.n_lights;
    s->d.root = (h.root < 0 && h.root != RT_ROOT_EMPTY) ? ~pos_of[(size_t)~h.root] : h.root;
    s->d.fast_ok = h.bounds_in_range;
