@@ -176,6 +176,10 @@ typedef struct rt_stats {
    /* most spawned rays / shadow items any wave held back at once (always filled); a frame that overflows the
     * lists is rendered again with longer ones, see attempts */
    uint64_t max_spawn_list;
+   /* RT_SCENE_COUNTERS, scenes with the second tree: closest-hit rays whose nearest primitive had no rival within the
+    * tie window and whose leaf the reference's walk provably reaches (answered without that walk); rays with a rival
+    * (the reference's walk was made); rays for which the reach of the leaf could not be shown (likewise) */
+   uint64_t hits_certified, hits_contested, hits_unreached;
 } rt_stats;
 
 typedef struct rt_scene_info {

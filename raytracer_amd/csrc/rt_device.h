@@ -191,7 +191,10 @@ __device__ __forceinline__ SlabAB slab_ab(const RayCtx &c, float mnx, float mny,
 /* the reference's answer from those two numbers */
 __device__ __forceinline__ float slab_value(const SlabAB &s)
 {
-   float res = (s.A < 0.0f && s.B > 0.0f && s.strict) ? s.B : (s.A < s.B ? s.A : -1.0f);
+   /* (selects, not branches: `&` keeps the compiler from turning the conditions into jumps) */
+   const bool inside = (s.A < 0.0f) & (s.B > 0.0f) & s.strict;
+   float res = s.A < s.B ? s.A : -1.0f;
+   res = inside ? s.B : res;
    return s.miss ? -1.0f : res;
 }
 template <bool PAR>

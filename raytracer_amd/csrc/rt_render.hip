@@ -118,7 +118,7 @@ struct SpawnRec {
 
 enum { ST_SHADOW_SKIPPED = 0, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES,
        ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
-       ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_LEAF_WAIT, ST_NO_RAY, ST_REFILLS, ST_CLK_REFILL, ST_CLK_NODE, ST_CLK_LEAF, ST_CLK_WAVE,
+       ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_CERT_OK, ST_CERT_RIVAL, ST_CERT_UNREACHED, ST_LEAF_WAIT, ST_NO_RAY, ST_REFILLS, ST_CLK_REFILL, ST_CLK_NODE, ST_CLK_LEAF, ST_CLK_WAVE,
        ST_ABORTED, ST_MAX_RAY_STEPS, ST_MAX_LIST, ST_OVERFLOW, ST_LIST_OVERFLOW,
        ST_CLOCK_FIRST_START, ST_CLOCK_LAST_EXIT, ST_CLOCK_EXIT_SUM, ST_WAVES,
 #ifdef RT_DEBUG_EXIT_HIST
@@ -549,6 +549,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    bool exhausted = n == 0;            /* wave-uniform: the queue has no more rays to fetch */
    bool wave_par = false;              /* wave-uniform: some lane may hold a ray with a parallel axis */
    bool wave_lit = false;              /* wave-uniform: some lane holds a ray the short box test is not valid for */
+   bool burst_filter = false;          /* wave-uniform: some lane of the current burst of node steps is in the second tree */
    RayCtx c;
    c.r.o = mk3(0, 0, 0); c.r.d = mk3(1, 1, 1); c.yx = c.yy = c.yz = 1.0f; c.par = 0; c.fast = true;
    float t = FLT_MAX, toBeat = -FLT_MAX;
@@ -570,6 +571,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    unsigned nvs = 0, nps = 0, nts = 0;                       /* COUNT only: the same for shadow feelers */
    unsigned ray_steps = 0, max_ray_steps = 0;   /* COUNT only: wave steps this ray has been in flight */
    unsigned long long clk_refill = 0, clk_node = 0, clk_leaf = 0;   /* COUNT only: 100 MHz ticks this wave spent in each part of its loop */
+   unsigned n_cert = 0, n_rival = 0, n_unreached = 0;   /* COUNT only: how this lane's closest-hit rays left the second tree with a hit */
    unsigned n_leafwait = 0, n_noray = 0, n_refills = 0;   /* COUNT only: node steps this lane sat out at a leaf / without a ray; refills of the wave */
 
    /* a ray is finished: scan the planes unless it left early, write its result */
@@ -581,6 +583,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
           * can tie with it or beat it -- provided it reaches the leaf at all; that is checked on the reference's tree,
           * along the one path from its root to that leaf.  Otherwise the reference's walk is made in full. */
          const bool alone = t > 2.0f * RT_EQ_EPS && !(t + RT_EQ_EPS > toBeat);
+         if (COUNT) { if (alone) n_cert++; else n_rival++; }
          if (alone) { mode = MODE_EXTEND | MODE_VERIFY; toBeat = __int_as_float(sc.leaf_parent[closest]); cur = sc.root; }
          else { mode = MODE_EXTEND; toBeat = -FLT_MAX; t = FLT_MAX; closest = -1; cur = sc.root; sp = 0; }
          return;
@@ -601,8 +604,10 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          Hit h; h.prim = closest; h.t = t; a.hits[idx] = h;
          if (OUT == OUT_CHAIN) {
             if (a.dur) a.dur[idx] = (unsigned)guard - born;
-            if (closest >= 0) pend = true;
-            else *reinterpret_cast<float4 *>(a.recs + idx) = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));   /* a miss: nothing to spawn */
+            if (closest >= 0) {
+               pend = true;
+               if (tag == 1) store_qray(a.rays, idx, c.r.o, c.r.d, -FLT_MAX, 1);      /* a primary: made on fetch, not stored then (bounce rays are, when they are spawned) */
+            } else *reinterpret_cast<float4 *>(a.recs + idx) = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));   /* a miss: nothing to spawn */
          }
       }
    };
@@ -662,7 +667,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          SlabAB sl = slab_ab<VARIANT == 1>(c, na.x, na.y, na.z, na.w, nb.x, nb.y);
          SlabAB sr = slab_ab<VARIANT == 1>(c, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w);
          left = slab_value(sl); right = slab_value(sr);
-         if (sc.filter_root != RT_ROOT_EMPTY) {
+         if (sc.filter_root != RT_ROOT_EMPTY && burst_filter) {
             /* a ray still in the miss filter's tree asks the filter's question of the same two numbers */
             const bool filtering = (mode & MODE_FILTER) != 0;
             float fl = slab_filter_value(sl), fr = slab_filter_value(sr);
@@ -689,7 +694,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             const int hangs_at = __float_as_int(toBeat);
             const bool right_turn = ch.y >= 0 ? hangs_at >= ch.y : ~ch.y == closest;
             if ((right_turn ? r : l) < t + RT_EQ_EPS) cur = right_turn ? ch.y : ch.x;      /* at the leaf: the leaf step ends the ray */
-            else { mode = MODE_EXTEND; toBeat = -FLT_MAX; t = FLT_MAX; closest = -1; cur = sc.root; sp = 0; }
+            else { mode = MODE_EXTEND; toBeat = -FLT_MAX; t = FLT_MAX; closest = -1; cur = sc.root; sp = 0; if (COUNT) { n_cert--; n_unreached++; } }
             return;
          }
       }
@@ -918,13 +923,12 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                   QRay q;
                   if (own) q = load_qray_written(a.rays, my);
                   else if (OUT == OUT_CHAIN) {
-                     /* generateCameraRays (kernel.cu:477-498) for sample slot `my`; the ray is also stored, for the
-                      * shadow items and the light sums that need it later */
+                     /* generateCameraRays (kernel.cu:477-498) for sample slot `my`; the ray goes into the queue only if it
+                      * hits something (the light sums need it then), see finish */
                      int X = 0, Y = 0;
                      bool inside = slot_to_sample(a.g, (unsigned)my, X, Y);
                      Ray pr; pr.o = mk3(0, 0, 0); pr.d = mk3(0, 0, 1);
                      if (inside) pr = camera_ray(a.cam, a.g, X, Y);
-                     store_qray(a.rays, my, pr.o, pr.d, -FLT_MAX, inside ? 1 : 0);
                      q.ox = pr.o.x; q.oy = pr.o.y; q.oz = pr.o.z; q.to_beat = -FLT_MAX;
                      q.dx = pr.d.x; q.dy = pr.d.y; q.dz = pr.d.z; q.valid = inside ? 1 : 0;
                      if (!inside) {
@@ -967,6 +971,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       /* ---- node steps ---- */
       /* the box-test variant is the same for a whole burst (the flags only change in a refill): one loop each */
       auto burst_loop = [&](auto variant_tag) {
+         /* no ray enters the second tree during a burst (that happens in refills and leaf steps) */
+         burst_filter = __ballot(active && (mode & MODE_FILTER)) != 0;
 #pragma unroll 1
          for (int burst = 0; burst < a.node_burst; burst++) {
             bool in_node = cur >= 0;                 /* idle lanes hold RT_CUR_IDLE */
@@ -1002,7 +1008,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                 * `closest` at t; on to the planes (the stack is empty, the pop below ends the ray) */
                mode = MODE_EXTEND; toBeat = -FLT_MAX; sp = 0;
                if (~cur == closest) tested = true;
-               else { t = FLT_MAX; closest = -1; cur = sc.root; }       /* not the leaf it set out for: the reference's walk in full */
+               else { t = FLT_MAX; closest = -1; cur = sc.root; if (COUNT) { n_cert--; n_unreached++; } }       /* not the leaf it set out for: the reference's walk in full */
             } else if (mode & MODE_FILTER) {
                /* still in the filter's tree: does the ray meet this primitive where it could matter? */
                bool shadow = OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND;
@@ -1088,6 +1094,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          stat_add(stats, ST_PRIM_TESTS_SHADOW, (unsigned long long)nps);
          stat_add(stats, ST_TIES_SHADOW, (unsigned long long)nts);
       }
+      stat_add(stats, ST_CERT_OK, (unsigned long long)n_cert); stat_add(stats, ST_CERT_RIVAL, (unsigned long long)n_rival);
+      stat_add(stats, ST_CERT_UNREACHED, (unsigned long long)n_unreached);
       stat_add(stats, ST_LEAF_WAIT, (unsigned long long)n_leafwait);
       stat_add(stats, ST_NO_RAY, (unsigned long long)n_noray);
       if (lane == 0) {
@@ -1280,6 +1288,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs,
    unsigned chain = 0;          /* the longest chain of dependent rays below (and with) the node just evaluated, in loop turns of its wave */
    node[0] = (int)i; stage[0] = 0;
    F3 ret = mk3(0.0f, 0.0f, 0.0f);
+   if (live) {
+      /* most trees are a single node: the same expression with both children absent, without the stack */
+      float4 rr = *reinterpret_cast<const float4 *>(recs + i);
+      if (__float_as_int(rr.z) < 0 && __float_as_int(rr.w) < 0) {
+         F3 total = mk3(totals[3 * i], totals[3 * i + 1], totals[3 * i + 2]);
+         const F3 none = mk3(0.0f, 0.0f, 0.0f);
+         ret = total * (1.0f - rr.x - rr.y) + rr.x * none + rr.y * none;
+         if (dur) chain = dur[i];
+         sp = -1;
+      }
+   }
    while (sp >= 0) {
       float4 rr = *reinterpret_cast<const float4 *>(recs + node[sp]);
       int child_refl = __float_as_int(rr.z), child_refr = __float_as_int(rr.w);
@@ -2114,6 +2133,8 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    st.wave_node_steps = sum_stat(s->h_stats, ST_WAVE_NODE_STEPS); st.wave_leaf_steps = sum_stat(s->h_stats, ST_WAVE_LEAF_STEPS);
    st.lane_steps_at_leaf = sum_stat(s->h_stats, ST_LEAF_WAIT); st.lane_steps_no_ray = sum_stat(s->h_stats, ST_NO_RAY);
    st.wave_refills = sum_stat(s->h_stats, ST_REFILLS);
+   st.hits_certified = sum_stat(s->h_stats, ST_CERT_OK); st.hits_contested = sum_stat(s->h_stats, ST_CERT_RIVAL);
+   st.hits_unreached = sum_stat(s->h_stats, ST_CERT_UNREACHED);
    {
       double w = (double)sum_stat(s->h_stats, ST_CLK_WAVE);
       st.wave_time_refill = w > 0 ? (float)((double)sum_stat(s->h_stats, ST_CLK_REFILL) / w) : 0.0f;

@@ -12,4 +12,5 @@ for name, spp, sh in (("balls2", 1, abi.RT_PHONG), ("bunny", 4, abi.RT_COOK_TORR
         ne = ct["rays_primary"] + ct["rays_reflect"] + ct["rays_refract"]
         ns = ct["rays_shadow"]
         print(f"{name} filter={filt}: extend rays {ne/1e6:.2f} M visits/ray {ct['node_visits']/max(1,ne):.1f} tests/ray {ct['prim_tests']/max(1,ne):.2f} ties {ct['tie_events']}; "
-              f"feelers {ns/1e6:.2f} M visits/ray {ct['node_visits_shadow']/max(1,ns):.1f} tests/ray {ct['prim_tests_shadow']/max(1,ns):.2f}; shade nodes {ct['shade_nodes']/1e6:.2f} M; trace {ct['ms_trace']:.2f} ms", flush=True)
+              f"feelers {ns/1e6:.2f} M visits/ray {ct['node_visits_shadow']/max(1,ns):.1f} tests/ray {ct['prim_tests_shadow']/max(1,ns):.2f}; shade nodes {ct['shade_nodes']/1e6:.2f} M; trace {ct['ms_trace']:.2f} ms; "
+              f"hits certified {ct['hits_certified']/1e6:.2f} M, with a rival {ct['hits_contested']/1e6:.2f} M, unreached {ct['hits_unreached']/1e6:.2f} M", flush=True)
