@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libraytracer_amd.so")
+# RT_LIBRARY names another build of the same library (A/B measurements); it is still this project's HIP library
+LIB_PATH = os.environ.get("RT_LIBRARY") or os.path.join(_HERE, "libraytracer_amd.so")
 
 # status codes (include/raytracer_amd.h)
 RT_OK = 0

@@ -562,7 +562,6 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
     * ([res_lo, res_hi)), and a wave sums its statistics in registers and adds them once, when it is done. */
    const unsigned long long n_patches = (a.n + 63ULL) >> 6;
    unsigned stream = (blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) % RT_FETCH_STREAMS;   /* wave-uniform: the stream this wave fetches from */
-   unsigned streams_dry = 0;                   /* wave-uniform: streams this wave has found dry */
    unsigned res_lo = 0, res_hi = 0;            /* wave-uniform: OUT_CHAIN, queue entries reserved, not yet used */
    bool res_full = false;                      /* wave-uniform: the queue had no entries left to reserve */
    unsigned n_skipped = 0;                     /* OUT_CHAIN: shadow feelers this lane did not have to trace */
@@ -571,6 +570,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    unsigned nvs = 0, nps = 0, nts = 0;                       /* COUNT only: the same for shadow feelers */
    unsigned ray_steps = 0, max_ray_steps = 0;   /* COUNT only: wave steps this ray has been in flight */
    unsigned long long clk_refill = 0, clk_node = 0, clk_leaf = 0;   /* COUNT only: 100 MHz ticks this wave spent in each part of its loop */
+#ifdef RT_DEBUG_REFILL_CLK
+   unsigned long long dbg_wait = 0, dbg_pre = 0, dbg_c = 0, dbg_d = 0;
+#endif
    unsigned n_cert = 0, n_rival = 0, n_unreached = 0;   /* COUNT only: how this lane's closest-hit rays left the second tree with a hit */
    unsigned n_leafwait = 0, n_noray = 0, n_refills = 0;   /* COUNT only: node steps this lane sat out at a leaf / without a ray; refills of the wave */
 
@@ -834,16 +836,10 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       if ((n_idle >= a.refill_idle || m_active == 0) && (!exhausted || list_count > 0 || any_pend)) {
          const unsigned long long clk0 = COUNT ? wall_clock64() : 0ULL;
          if (COUNT) n_refills++;
-         /* What this wave stored in earlier refills (list entries, queue entries, shaded points) is read back below, by
-          * other lanes of the wave: those stores are complete first.  They were issued at least a burst of node steps
-          * ago, so this costs nothing; a fence behind the stores themselves cost a memory round trip per refill. */
-         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
          /* what the lanes that finished since the last refill spawn: a lane with a bounce ray goes on with it, the rest
           * goes onto the list */
          if (any_pend) {
-            const bool front = spawn_stage();
-            /* entries put at the front are taken below, by other lanes: their rays have to be in memory first */
-            if (front) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            (void)spawn_stage();
             m_active = __ballot(active);
             n_idle = 64 - __popcll(m_active);
          }
@@ -861,6 +857,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
           * their order. */
          unsigned long long q_raw = 0;
          if (need > 0 && lane == 0) q_raw = atomicAdd(a.next + (size_t)stream * 8, (unsigned long long)need);
+         /* What this wave stored earlier (list entries, queue entries, shaded points) is read back below, by other lanes
+          * of the wave: those stores are complete first.  Only a refill that takes list entries reads anything back. */
+         if (take > 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
          uint2 item = make_uint2(0u, 0u);
          const bool own = !active && rank < take;
          if (own) item = list_get(rank);
@@ -868,12 +867,33 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          list_count -= take;
          unsigned long long q_base = 0, q_len = 0;
          const unsigned my_stream = stream;
+#ifdef RT_DEBUG_REFILL_CLK
+         const unsigned long long clkA = wall_clock64();
+#endif
          if (need > 0) {
             q_base = __shfl(q_raw, 0);
+#ifdef RT_DEBUG_REFILL_CLK
+            if (COUNT) { asm volatile("" : "+v"(q_base)); dbg_wait += wall_clock64() - clkA; dbg_pre += clkA - clk0; }
+#endif
             q_len = n_patches > stream ? ((n_patches - stream + RT_FETCH_STREAMS - 1) / RT_FETCH_STREAMS) * 64ULL : 0ULL;
             if (q_base + (unsigned long long)need >= q_len) {
-               stream = stream + 1 == RT_FETCH_STREAMS ? 0u : stream + 1;
-               if (++streams_dry == RT_FETCH_STREAMS) exhausted = true;
+               /* This stream has run dry.  One look at all the counters (lane i reads stream i's) says which streams
+                * still have slots: the wave moves to the next of those, or is done fetching.  A counter only grows, so
+                * a stream seen dry stays dry; one seen live may be dry by the time the wave asks it, and then the wave
+                * looks again. */
+               static_assert(RT_FETCH_STREAMS == 64, "one lane per stream");
+               const unsigned long long seen = __hip_atomic_load(a.next + (size_t)lane * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+               const unsigned long long len_i = n_patches > lane ? ((n_patches - lane + RT_FETCH_STREAMS - 1) / RT_FETCH_STREAMS) * 64ULL : 0ULL;
+               unsigned long long live = __ballot(seen < len_i) & ~(1ULL << stream);
+               if (live == 0) exhausted = true;
+               else {
+                  /* the waves that leave a dry stream spread over the live ones (all on the nearest one, they would
+                   * queue at its counter) */
+                  const unsigned wave_id = blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6);
+                  const unsigned pick = wave_id % (unsigned)__popcll(live);
+                  const unsigned long long sel = __ballot(((live >> lane) & 1ULL) != 0 && (unsigned)__popcll(live & below) == pick);
+                  stream = (unsigned)__builtin_ctzll(sel);
+               }
             }
          }
          bool put_back = false;
@@ -919,6 +939,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                      my = (unsigned long long)a.tile_order[k] * a.g.per_tile + (f - k * a.g.per_tile);
                   }
                }
+#ifdef RT_DEBUG_REFILL_CLK
+               if (COUNT) { asm volatile("" : "+v"(my)); dbg_c += wall_clock64() - clk0; }
+#endif
                if (have) {
                   QRay q;
                   if (own) q = load_qray_written(a.rays, my);
@@ -937,6 +960,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                         *reinterpret_cast<float4 *>(a.recs + my) = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));
                      }
                   } else q = load_qray_rec(a.rays, my);
+#ifdef RT_DEBUG_REFILL_CLK
+                  if (COUNT) { asm volatile("" : "+v"(q.dx), "+v"(q.ox)); dbg_d += wall_clock64() - clk0; }
+#endif
                   if (q.valid) {
                      Ray r; r.o = mk3(q.ox, q.oy, q.oz); r.d = mk3(q.dx, q.dy, q.dz);
                      c = make_ctx(r);
@@ -1094,6 +1120,10 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          stat_add(stats, ST_PRIM_TESTS_SHADOW, (unsigned long long)nps);
          stat_add(stats, ST_TIES_SHADOW, (unsigned long long)nts);
       }
+#ifdef RT_DEBUG_REFILL_CLK
+      if (lane == 0) printf("");
+      if (lane == 0 && blockIdx.x == 7 && threadIdx.x == 0) printf("refill ticks: total %llu, before the counter %llu, waiting for it %llu, slot known at %llu, ray made at %llu, refills %u\n", clk_refill, dbg_pre, dbg_wait, dbg_c, dbg_d, n_refills);
+#endif
       stat_add(stats, ST_CERT_OK, (unsigned long long)n_cert); stat_add(stats, ST_CERT_RIVAL, (unsigned long long)n_rival);
       stat_add(stats, ST_CERT_UNREACHED, (unsigned long long)n_unreached);
       stat_add(stats, ST_LEAF_WAIT, (unsigned long long)n_leafwait);
