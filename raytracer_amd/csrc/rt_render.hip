@@ -347,24 +347,24 @@ __device__ __forceinline__ Ray camera_ray(const DCamera &cam, const DGrid &g, in
  * division's range (RayCtx::fast false; no ordinary scene has one).
  *
  * OUT_HIT    a plain queue of rays: writes the closest hit of ray i to hits[i] (toBeat early-out honoured).
- * OUT_CHAIN  the whole shade forest of the first n rays (the primaries) in one launch.  When a ray has found
- *            its hit, three kinds of follow-up work go onto a per-wave list (a ring in global memory), which
- *            the wave's idle lanes drain, oldest entry first, before they fetch new primaries:
- *              - its reflection and refraction rays (getReflection / getRefraction, kernel.cu:209-276,
- *                guarded as in kernel.cu:361-371), appended to the same queue behind the primaries (one
- *                atomic per wave for the indices; valid = depth level + 1);
- *              - one shadow item (isInShadow, kernel.cu:202-207, 347-352): a lane that takes it traces the
- *                feeler of the node's next light and, while lights remain, puts the item back for another
- *                lane.  The feeler's own-surface test (kernel.cu:351) is an ordinary leaf step: the lane
- *                starts at the leaf of the shaded primitive in MODE_SETUP and moves to the root with the
- *                result as its toBeat.
- *            Oldest first, because newest first lets an old entry (and the subtree behind it) wait until the
- *            primaries have run dry; the price is a list that grows with the breadth of the forest, which is
- *            why it lives in global memory and a frame that overflows it is rendered again with longer lists.
- *            Primaries are fetched tile by tile in the order the host passes (tiles whose bounce trees were
- *            deepest in the previous frame first), so that the last primaries of a launch start short chains.
- *            No data is handed between waves, so there is nothing to wait for and every wave's exit is its
- *            own: primaries dry, list empty, lanes idle. */
+ * OUT_CHAIN  the whole shade forest of the first n rays (the primaries) in one launch.  When a ray has found its
+ *            hit, its follow-up work is started at the wave's next refill:
+ *              - its reflection and refraction rays (getReflection / getRefraction, kernel.cu:209-276, guarded as in
+ *                kernel.cu:361-371), appended to the same queue behind the primaries (entries reserved a range at a
+ *                time; valid = depth level + 1).  The lane goes on with one of them itself, at once; a second one
+ *                goes to the front of a per-wave list (a ring in global memory);
+ *              - one shadow item (isInShadow, kernel.cu:202-207, 347-352), to the back of that list: a lane that takes
+ *                it traces the feeler of the node's next light and, while lights remain, puts the item back for
+ *                another lane.  The feeler's own-surface test (kernel.cu:351) is an ordinary leaf step: the lane
+ *                starts at the leaf of the shaded primitive in MODE_SETUP and moves to the root with the result as
+ *                its toBeat.
+ *            Idle lanes drain the list, front first, before they fetch new primaries.  Bounce rays never queue behind
+ *            shadow items: they are the launch's longest dependent chains.  The list grows with the breadth of the
+ *            forest, which is why it lives in global memory and a frame that overflows it is rendered again with
+ *            longer lists.  Primaries are fetched tile by tile in the order the host passes (tiles whose chains of
+ *            dependent rays took longest in the previous frame first), so that the last primaries of a launch start
+ *            short chains.  No data is handed between waves, so there is nothing to wait for and every wave's exit is
+ *            its own: primaries dry, list empty, lanes idle. */
 enum { OUT_HIT = 0, OUT_CHAIN = 2 };
 enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2, MODE_KIND = 3,
        MODE_FILTER = 4,     /* set while the ray is still in the second tree (see enter_tree below) */
@@ -415,6 +415,7 @@ struct TraceArgs {
    const int *tile_order;       /* when non-null: the order in which the launch's tiles are started (costliest first) */
    StackEntry *spill;           /* SPILL kernels: stack entries beyond the RT_LDS_STACK kept in LDS, [entry - RT_LDS_STACK][lane of the launch] */
    unsigned *dur;               /* when non-null: per queue entry, how many turns of its wave's loop the closest-hit ray was in flight */
+   unsigned *tile_bounce;       /* when non-null: per tile of the launch (zeroed), set when a primary of the tile spawns a bounce ray */
 };
 
 __device__ __forceinline__ QRay load_qray_rec(const QRay *q, unsigned long long i)
@@ -707,12 +708,17 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       if (goR || goL) cur = goR ? ch.y : ch.x;
       else pop(top, cut);
    };
-   /* A ray starts its walk.  With a miss filter it first walks the filter's tree (never pruned by t: t stays FLT_MAX)
-    * looking for any primitive it meets at a parameter the reference would accept -- for a feeler: one that could make it
-    * shadowed, i.e. closer than its target by more than EPSILON.  None: the reference's walk would end as it began (no
-    * hit; for a feeler, nothing in front of the target), so the ray is finished as if that walk had been made.  One: the
-    * ray leaves the filter and makes the reference's walk from the root, unchanged.  Rays outside the short box test's
-    * range do not use the filter. */
+   /* A ray starts its walk.  Beside the reference's tree the scene may hold a second one: a surface-area tree over the
+    * same primitive boxes, every box widened.  Nothing is answered from it; it is used to prove what the reference's
+    * walk returns, and that walk is made whenever the proof does not go through.
+    *  - A ray that meets no primitive there at a parameter the reference would accept (a feeler: none in front of its
+    *    target by more than EPSILON) is finished as if the reference's walk had been made: that walk would end as it
+    *    began, whatever its order.
+    *  - A closest-hit ray keeps the nearest primitive it meets there and the nearest of the others; finish() decides
+    *    from those whether the reference's walk can be replaced by the path to that primitive's leaf.
+    *  - A feeler that meets a primitive in front of its target leaves the second tree and makes the reference's walk
+    *    from its root, unchanged.
+    * Rays outside the short box test's range do not use the second tree. */
    auto enter_tree = [&]() {
       if (sc.filter_root != RT_ROOT_EMPTY && c.fast && !wave_lit) {
          cur = sc.filter_root; mode |= MODE_FILTER;
@@ -807,6 +813,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             w_refl += cR; w_refr += cT;
             if (nR + nT != cnt && lane == 0) stat_add(stats, ST_OVERFLOW, 1ULL);   /* the queue is full: the host retries with a larger one */
             cont_refl = okR; cont_refr = okT && !okR;
+            /* a tile none of whose primaries spawns anything is shaded and resolved in one pass (k_resolve) */
+            if (a.tile_bounce && tag == 1 && (okR || okT)) a.tile_bounce[fd_div(idx, a.g.per_tile_div)] = 1u;
          }
       }
       if (pend) *reinterpret_cast<float4 *>(a.recs + idx) = make_float4(out.refl, out.alpha, __int_as_float(out.child_refl), __int_as_float(out.child_refr));
@@ -958,6 +966,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                         /* a slot outside the frame: the result of a miss, no follow-up work */
                         Hit h; h.prim = -1; h.t = FLT_MAX; a.hits[my] = h;
                         *reinterpret_cast<float4 *>(a.recs + my) = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));
+                        if (a.dur) a.dur[my] = 0u;
                      }
                   } else q = load_qray_rec(a.rays, my);
 #ifdef RT_DEBUG_REFILL_CLK
@@ -1272,14 +1281,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_begin_chunk(unsigned long long *st
 
 /* light: totalLight of every node, the loop of kernel.cu:347-358 with the shadow flags, over every queue entry
  * some wave reserved (entries reserved and not used read as a miss) */
-__global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue, const Hit *hits, const unsigned *flag_words, unsigned flag_stride,
-                                                    const unsigned *n_dev, unsigned cap, int shading, float *totals)
+__device__ __forceinline__ F3 light_sum(const DScene &sc, const QRay *queue, long long i, Hit h, const unsigned *flag_words, unsigned flag_stride,
+                                        int shading)
 {
-   long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-   unsigned reserved = *n_dev;
-   unsigned n = reserved < cap ? reserved : cap;
-   if (i >= (long long)n) return;
-   Hit h = hits[i];
    F3 total = mk3(0.0f, 0.0f, 0.0f);
    if (h.prim >= 0) {
       ShadePoint sp = shade_point(sc, queue, i, h);
@@ -1298,6 +1302,21 @@ __global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue
          total = total + c;
       }
    }
+   return total;
+}
+
+/* `tile_bounce` (may be null): primaries of a tile whose flag is clear are left to k_resolve, which shades them itself
+ * (a wave's 64 entries lie in one tile: per_tile is a multiple of 64 whenever the flags are in use) */
+__global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue, const Hit *hits, const unsigned *flag_words, unsigned flag_stride,
+                                                    const unsigned *n_dev, unsigned cap, int shading, float *totals,
+                                                    const unsigned *tile_bounce, unsigned n_primary, unsigned per_tile)
+{
+   long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+   unsigned reserved = *n_dev;
+   unsigned n = reserved < cap ? reserved : cap;
+   if (i >= (long long)n) return;
+   if (tile_bounce && i < (long long)n_primary && tile_bounce[(unsigned)i / per_tile] == 0u) return;
+   F3 total = light_sum(sc, queue, i, hits[i], flag_words, flag_stride, shading);
    totals[3 * i] = total.x; totals[3 * i + 1] = total.y; totals[3 * i + 2] = total.z;
 }
 
@@ -1307,9 +1326,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue
  * 2^RT_MAX_RECURSE - 1 nodes, usually a short chain) with an explicit stack of one frame per level, so every
  * node is evaluated once, by one thread, in the reference's operand order: no atomics, no races. */
 __global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs, const float *totals, const unsigned *dur, long long n_primary, float *rgb,
-                                                           unsigned *tile_cost, unsigned per_tile)
+                                                           unsigned *tile_cost, unsigned per_tile, const unsigned *tile_bounce)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+   /* tiles without a bounce ray are left to k_resolve (a wave's 64 primaries lie in one tile) */
+   if (tile_bounce && i < n_primary && tile_bounce[(unsigned)i / per_tile] == 0u) return;
    const bool live = i < n_primary;
    int node[RT_MAX_RECURSE], stage[RT_MAX_RECURSE];
    float rx[RT_MAX_RECURSE], ry[RT_MAX_RECURSE], rz[RT_MAX_RECURSE];
@@ -1375,8 +1396,18 @@ __device__ __forceinline__ unsigned char to_byte(float v)
 }
 
 /* resolve: averageBufferColors, kernel.cu:545-570.  Thread = pixel of a batch tile. */
+/* What k_light and k_combine_tree leave to this kernel: the tiles none of whose primaries spawned a bounce ray
+ * (`tile_bounce` clear).  Every tree there is a single node, so a sample's colour is its own light sum times
+ * (1 - refl - alpha) -- the same functions and the same expression as in those kernels, evaluated here, where the
+ * samples are averaged anyway: such a tile's hits and spawn records are read once and nothing is written in between. */
+struct ResolveShade {
+   DScene sc;
+   const QRay *queue; const Hit *hits; const SpawnRec *recs; const unsigned *flag_words; unsigned flag_stride; int shading;
+   const unsigned *tile_bounce;     /* null: every tile went through k_light and k_combine_tree */
+   const unsigned *dur; unsigned *tile_cost;
+};
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DGrid g, const float *rgb, int n_batch_tiles, int out_layout,
-                                                      uchar4 *out)
+                                                      uchar4 *out, ResolveShade rs)
 {
    long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
    const int T = RT_TILE;
@@ -1387,16 +1418,41 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DGrid g, const float *rgb,
    int tile = g.tile_first + (g.k0 + k) * g.tile_stride;
    int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
    int x = tx * T + lx, y = ty * T + ly;
-   if (x >= g.width || y >= g.height) return;
+   const bool here = rs.tile_bounce && rs.tile_bounce[k] == 0u;     /* uniform over the workgroup: 256 threads are a quarter of a tile */
+   const bool inside = x < g.width && y < g.height;
+   if (!inside && !here) return;
    F3 end = mk3(0.0f, 0.0f, 0.0f);
    long long tile_base = (long long)k * g.ts * g.ts;
+   unsigned cost = 0, sum = 0;
    for (int xo = 0; xo < g.sroot; xo++) {
       for (int yo = 0; yo < g.sroot; yo++) {
          int sx = lx * g.sroot + xo, sy = ly * g.sroot + yo;
          long long slot = tile_base + ((long long)((sy >> 3) * g.patches_per_row + (sx >> 3)) << 6) + ((sy & 7) << 3) + (sx & 7);
-         end = end + mk3(rgb[3 * slot], rgb[3 * slot + 1], rgb[3 * slot + 2]);
+         if (here) {
+            if (inside) {
+               const Hit h = rs.hits[slot];
+               if (h.prim >= 0) {
+                  /* (a sample that hit nothing has light sum 0 and weights 0, 0: its colour is +0 and adds nothing) */
+                  float4 rr = *reinterpret_cast<const float4 *>(rs.recs + slot);
+                  F3 total = light_sum(rs.sc, rs.queue, slot, h, rs.flag_words, rs.flag_stride, rs.shading);
+                  const F3 none = mk3(0.0f, 0.0f, 0.0f);
+                  F3 ret = total * (1.0f - rr.x - rr.y) + rr.x * none + rr.y * none;       /* kernel.cu:375-376 without children */
+                  end = end + mk3(clamp01(ret.x), clamp01(ret.y), clamp01(ret.z));          /* kernel.cu:537-539 */
+               }
+               if (rs.dur) { unsigned d = rs.dur[slot]; cost = d > cost ? d : cost; sum += d; }
+            }
+         } else end = end + mk3(rgb[3 * slot], rgb[3 * slot + 1], rgb[3 * slot + 2]);
       }
    }
+   if (here && rs.tile_cost) {
+      /* the tile's cost for the next frame's start order, as k_combine_tree records it for the other tiles */
+      for (int o = 32; o > 0; o >>= 1) { unsigned other = __shfl_xor(cost, o); cost = other > cost ? other : cost; sum += __shfl_xor(sum, o); }
+      if ((threadIdx.x & 63) == 0 && cost) {
+         atomicMax(&rs.tile_cost[2 * (unsigned)k], cost);
+         atomicAdd(&rs.tile_cost[2 * (unsigned)k + 1], sum);
+      }
+   }
+   if (!inside) return;
    float div = (float)(g.sroot * g.sroot);
    end = mk3(end.x / div, end.y / div, end.z / div);
    end = end * 255.0f;
@@ -1493,6 +1549,7 @@ struct rt_scene {
    int refill_idle, node_burst, leaf_trigger, use_tile_order, order_classes;
    double order_mean_weight;
    unsigned reserve;        /* queue entries a wave reserves at a time for its bounce rays */
+   int fuse_resolve;        /* tiles without bounce rays are shaded by k_resolve itself */
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1852,6 +1909,7 @@ static void scene_tuning(rt_scene *s)
    s->use_tile_order = env_int("RT_TILE_ORDER", 1, true);
    s->order_classes = env_int("RT_ORDER_CLASSES", RT_ORDER_CLASSES, false);
    s->order_mean_weight = (double)env_int("RT_ORDER_MEAN_WEIGHT", RT_ORDER_MEAN_WEIGHT, true);
+   s->fuse_resolve = env_int("RT_FUSE_RESOLVE", 1, true);
    int r = env_int("RT_RESERVE", RT_RESERVE, false);
    s->reserve = (unsigned)(r < 128 ? 128 : r);      /* one spawn stage can ask for 128 entries */
 }
@@ -1985,6 +2043,9 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       const unsigned flag_stride = (unsigned)((L > 0 ? L : 1) + 31) / 32u;
       const size_t flag_bytes = sizeof(unsigned) * (size_t)flag_stride * (size_t)cap;
       const size_t o_flags = carve(flag_bytes);
+      /* per tile of a chunk: did a primary of the tile spawn a bounce ray?  Tiles where none did are shaded in k_resolve */
+      const bool fuse = view == VIEW_FRAME && s->fuse_resolve;
+      const size_t o_bounce = carve(sizeof(unsigned) * (size_t)chunk_tiles);
       const size_t slice = used;
       if (slice * (size_t)ring > s->arena.cap) { int rc = arena_reserve(s->arena, slice * (size_t)ring); if (rc != RT_OK) return rc; }
       { int rc = ensure_lists(s); if (rc != RT_OK) return rc; }
@@ -2048,6 +2109,10 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
                a.tile_order = s->d_tile_order;
             }
             if (track_cost) a.dur = AT(unsigned, r, o_dur);
+            if (fuse) {
+               a.tile_bounce = AT(unsigned, r, o_bounce);
+               HIP_TRY(hipMemsetAsync(a.tile_bounce, 0, sizeof(unsigned) * (size_t)nb, S));
+            }
             Timer &tm = ev.begin(S, &st.ms_trace);
             launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, S);
             ev.end(tm, S); st.launches_trace++;
@@ -2060,24 +2125,31 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             Timer &tm = ev.begin(S, &st.ms_light);
             hipLaunchKernelGGL(k_light, dim3(grid_for(cap)), dim3(RT_BLOCK), 0, S, sc, (const QRay *)queue, (const Hit *)hits,
                                (const unsigned *)AT(unsigned, r, o_flags), flag_stride, (const unsigned *)ctr.tail, cap,
-                               p->shading, AT(float, r, o_totals));
+                               p->shading, AT(float, r, o_totals), fuse ? (const unsigned *)AT(unsigned, r, o_bounce) : (const unsigned *)nullptr,
+                               (unsigned)np, (unsigned)per_tile);
             ev.end(tm, S);
             Timer &tc = ev.begin(S, &st.ms_combine);
             hipLaunchKernelGGL(k_combine_tree, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, (const SpawnRec *)recs,
                                (const float *)AT(float, r, o_totals), track_cost ? (const unsigned *)AT(unsigned, r, o_dur) : (const unsigned *)nullptr, np, AT(float, r, o_rgb),
-                               track_cost ? s->d_tile_cost : (unsigned *)nullptr, (unsigned)per_tile);
+                               track_cost ? s->d_tile_cost : (unsigned *)nullptr, (unsigned)per_tile,
+                               fuse ? (const unsigned *)AT(unsigned, r, o_bounce) : (const unsigned *)nullptr);
             ev.end(tc, S);
-            if (track_cost) HIP_TRY(hipMemcpyAsync(s->h_tile_cost, s->d_tile_cost, 2 * sizeof(unsigned) * (size_t)n_sel, hipMemcpyDeviceToHost, S));
          }
          if (view == VIEW_FRAME) {
             Timer &tr = ev.begin(S, &st.ms_resolve);
             long long npx = nb * RT_TILE * RT_TILE;
+            ResolveShade rs; memset(&rs, 0, sizeof rs);
+            rs.sc = sc; rs.queue = queue; rs.hits = hits; rs.recs = recs; rs.flag_words = AT(unsigned, r, o_flags); rs.flag_stride = flag_stride;
+            rs.shading = p->shading; rs.tile_bounce = fuse ? AT(unsigned, r, o_bounce) : nullptr;
+            rs.dur = track_cost ? AT(unsigned, r, o_dur) : nullptr; rs.tile_cost = track_cost ? s->d_tile_cost : nullptr;
             hipLaunchKernelGGL(k_resolve, dim3(grid_for(npx)), dim3(RT_BLOCK), 0, S, g, (const float *)AT(float, r, o_rgb), (int)nb,
-                               p->out_layout, (uchar4 *)out_dev);
+                               p->out_layout, (uchar4 *)out_dev, rs);
             ev.end(tr, S);
          } else {
             hipLaunchKernelGGL(k_unslot_rgb, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, g, (const float *)AT(float, r, o_rgb), np, rgb_dev);
          }
+         /* the tile costs are complete once the last kernel that adds to them has run */
+         if (track_cost && view != VIEW_PRIMARY) HIP_TRY(hipMemcpyAsync(s->h_tile_cost, s->d_tile_cost, 2 * sizeof(unsigned) * (size_t)n_sel, hipMemcpyDeviceToHost, S));
          HIP_TRY(hipGetLastError());
       }
 #undef AT
