@@ -23,6 +23,7 @@
 #include <map>
 #include <string>
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -289,7 +290,9 @@ struct SahBuilder {
    std::vector<TreeNode> &pool;
    enum { BINS = 16 };
 
-   int build(int first, int last, int depth_left)     /* [first, last) */
+   /* `par`: how many more levels hand their right half to another thread (large ranges only).  The halves work on
+    * disjoint ranges of `ids` and on node pools of their own; the tree is the same whatever `par` is. */
+   int build(int first, int last, int depth_left, int par = 0)     /* [first, last) */
    {
       int n = last - first;
       if (n == 1) { int p = ids[(size_t)first]; pool.push_back(TreeNode{-1, -1, p, boxes[(size_t)p]}); return (int)pool.size() - 1; }
@@ -348,8 +351,27 @@ struct SahBuilder {
             return ca < cb2 || (ca == cb2 && a < b);
          });
       }
-      int l = build(first, mid, depth_left - 1);
-      int r = build(mid, last, depth_left - 1);
+      int l, r;
+      if (par > 0 && n >= 2048) {
+         std::vector<TreeNode> other_pool;
+         other_pool.reserve((size_t)(2 * (last - mid)));
+         SahBuilder other{boxes, ids, other_pool};
+         int r_local = -1;
+         bool threaded = true;
+         std::thread worker;
+         try { worker = std::thread([&]() { r_local = other.build(mid, last, depth_left - 1, par - 1); }); } catch (...) { threaded = false; }
+         l = build(first, mid, depth_left - 1, par - 1);
+         if (threaded) worker.join(); else r_local = other.build(mid, last, depth_left - 1, 0);
+         const int off = (int)pool.size();
+         for (TreeNode nd : other_pool) {
+            if (nd.prim < 0) { nd.left += off; nd.right += off; }
+            pool.push_back(nd);
+         }
+         r = r_local + off;
+      } else {
+         l = build(first, mid, depth_left - 1, 0);
+         r = build(mid, last, depth_left - 1, 0);
+      }
       pool.push_back(TreeNode{l, r, -1, unite(pool[(size_t)l].bb, pool[(size_t)r].bb)});
       return (int)pool.size() - 1;
    }
@@ -443,6 +465,51 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
    std::vector<int32_t> order((size_t)(n > 0 ? n : 1)), tmp((size_t)(n > 0 ? n : 1));
    for (int i = 0; i < n; i++) order[(size_t)i] = i;
 
+   /* The second tree: beside the reference's tree, a surface-area tree over the same primitive boxes, every box
+    * widened a little.  It decides nothing the reference decides; the traversal kernel uses it to prove what the
+    * reference's walk returns (no primitive met; or this one primitive, with no rival near it), and walks the reference's
+    * tree for every ray it cannot prove that for.  Built only beside the reference's tree, and on a thread of its own
+    * while that one is built here: the two read the same boxes and share nothing else. */
+   std::vector<rt_bvh_node> filter;
+   int filter_depth = 0;
+   int filter_min = RT_FILTER_MIN_PRIMS;
+   if (const char *e = getenv("RT_FILTER_MIN_PRIMS")) { if (atoi(e) >= 2) filter_min = atoi(e); }     /* tests lower it to put small scenes through the filter */
+   const bool want_filter = n >= filter_min && !(flags & (RT_SCENE_FAST_BVH | RT_SCENE_GPU_BVH | RT_SCENE_NO_FILTER));
+   auto build_filter = [&]() {
+      try {
+      std::vector<int32_t> ids((size_t)n);
+      for (int i = 0; i < n; i++) ids[(size_t)i] = i;
+      std::vector<TreeNode> pool;
+      pool.reserve((size_t)(2 * n));
+      int levels = 0; while ((1 << levels) < n) levels++;
+      SahBuilder sb{b.boxes, ids, pool};
+      /* no deeper than the traversal stack's share of LDS where the primitive count allows that: a tree that pushed
+       * the stack into global memory would cost more than its better splits win */
+      int budget = levels + 2 > RT_FILTER_DEPTH ? levels + 2 : RT_FILTER_DEPTH;
+      int root_node = sb.build(0, n, budget, 3);
+      if (pool[(size_t)root_node].prim < 0) {
+         flatten_tree(pool, root_node, filter, &filter_depth);
+         /* Every box of this tree contains the reference's own (padded) boxes of the primitives below it.  It is
+          * widened by 1e-4 plus a few units in the last place of its coordinates, far more than the rounding of the
+          * box test, so that a ray the reference's test lets into a primitive's own box is never turned away here. */
+         for (size_t k = 0; k < filter.size(); k++) {
+            float *v = filter[k].lmin;      /* lmin, lmax, rmin, rmax */
+            for (int j = 0; j < 12; j++) {
+               const float pad = 1e-4f + 8e-6f * std::fabs(v[j]);
+               const bool is_max = (j / 3) & 1;
+               v[j] = is_max ? v[j] + pad : v[j] - pad;
+            }
+         }
+      }
+      } catch (...) { filter.clear(); filter_depth = 0; }      /* out of memory: the scene goes without */
+   };
+   std::thread filter_thread;
+   struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{filter_thread};
+   bool filter_inline = false;
+   if (want_filter) {
+      try { filter_thread = std::thread(build_filter); } catch (...) { filter_inline = true; }
+   }
+
    std::vector<rt_bvh_node> flat;
    int32_t root = RT_ROOT_EMPTY;
    int depth = 0;
@@ -453,7 +520,7 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
       pool.reserve((size_t)(2 * n));
       int levels = 0; while ((1 << levels) < n) levels++;
       SahBuilder sb{b.boxes, order, pool};
-      int root_node = sb.build(0, n, levels + 8);
+      int root_node = sb.build(0, n, levels + 8, 3);
       if (pool[(size_t)root_node].prim >= 0) root = ~pool[(size_t)root_node].prim;
       else { flatten_tree(pool, root_node, flat, &depth); root = 0; }
    } else if (n > 0) {
@@ -515,40 +582,8 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
       }
    }
 
-   /* The miss filter: beside the reference's tree, a surface-area tree over the same primitive boxes, every box
-    * widened a little.  It decides nothing the reference decides; the traversal kernel only uses it to prove that a ray
-    * meets no primitive at all (then the reference's walk would come back empty-handed too, whatever its order), and
-    * walks the reference's tree for every ray it cannot prove that for.  Built only beside the reference's tree. */
-   std::vector<rt_bvh_node> filter;
-   int filter_depth = 0;
-   int filter_min = RT_FILTER_MIN_PRIMS;
-   if (const char *e = getenv("RT_FILTER_MIN_PRIMS")) { if (atoi(e) >= 2) filter_min = atoi(e); }     /* tests lower it to put small scenes through the filter */
-   if (n >= filter_min && !(flags & (RT_SCENE_FAST_BVH | RT_SCENE_GPU_BVH | RT_SCENE_NO_FILTER))) {
-      std::vector<int32_t> ids((size_t)n);
-      for (int i = 0; i < n; i++) ids[(size_t)i] = i;
-      std::vector<TreeNode> pool;
-      pool.reserve((size_t)(2 * n));
-      int levels = 0; while ((1 << levels) < n) levels++;
-      SahBuilder sb{b.boxes, ids, pool};
-      /* no deeper than the traversal stack's share of LDS where the primitive count allows that: a filter that pushed
-       * the stack into global memory would cost more than its better splits win */
-      int budget = levels + 2 > RT_FILTER_DEPTH ? levels + 2 : RT_FILTER_DEPTH;
-      int root_node = sb.build(0, n, budget);
-      if (pool[(size_t)root_node].prim < 0) {
-         flatten_tree(pool, root_node, filter, &filter_depth);
-         /* Every box of this tree contains the reference's own (padded) boxes of the primitives below it.  It is
-          * widened by 1e-4 plus a few units in the last place of its coordinates, far more than the rounding of the
-          * box test, so that a ray the reference's test lets into a primitive's own box is never turned away here. */
-         for (size_t k = 0; k < filter.size(); k++) {
-            float *v = filter[k].lmin;      /* lmin, lmax, rmin, rmax */
-            for (int j = 0; j < 12; j++) {
-               const float pad = 1e-4f + 8e-6f * std::fabs(v[j]);
-               const bool is_max = (j / 3) & 1;
-               v[j] = is_max ? v[j] + pad : v[j] - pad;
-            }
-         }
-      }
-   }
+   if (filter_inline) build_filter();
+   if (filter_thread.joinable()) filter_thread.join();
 
    std::vector<rt_dev_light> lights((size_t)d->n_lights);
    for (int i = 0; i < d->n_lights; i++) {
