@@ -1311,13 +1311,23 @@ __global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue
                                                     const unsigned *n_dev, unsigned cap, int shading, float *totals,
                                                     const unsigned *tile_bounce, unsigned n_primary, unsigned per_tile)
 {
-   long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+   /* one workgroup per tile for the primaries (a tile left to k_resolve costs one look at its flag), then one per 256
+    * of the entries behind them */
+   const unsigned n_tiles = n_primary / per_tile;
    unsigned reserved = *n_dev;
    unsigned n = reserved < cap ? reserved : cap;
-   if (i >= (long long)n) return;
-   if (tile_bounce && i < (long long)n_primary && tile_bounce[(unsigned)i / per_tile] == 0u) return;
-   F3 total = light_sum(sc, queue, i, hits[i], flag_words, flag_stride, shading);
-   totals[3 * i] = total.x; totals[3 * i + 1] = total.y; totals[3 * i + 2] = total.z;
+   long long first, last, step = RT_BLOCK;
+   if (blockIdx.x < n_tiles) {
+      if (tile_bounce && tile_bounce[blockIdx.x] == 0u) return;
+      first = (long long)blockIdx.x * per_tile + threadIdx.x; last = (long long)(blockIdx.x + 1) * per_tile;
+   } else {
+      first = (long long)n_primary + (long long)(blockIdx.x - n_tiles) * RT_BLOCK + threadIdx.x; last = first + 1;
+   }
+   if (last > (long long)n) last = (long long)n;
+   for (long long i = first; i < last; i += step) {
+      F3 total = light_sum(sc, queue, i, hits[i], flag_words, flag_stride, shading);
+      totals[3 * i] = total.x; totals[3 * i + 1] = total.y; totals[3 * i + 2] = total.z;
+   }
 }
 
 /* combine: the colour of primary i from the light sums of its bounce tree, children before parents:
@@ -1328,61 +1338,62 @@ __global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue
 __global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs, const float *totals, const unsigned *dur, long long n_primary, float *rgb,
                                                            unsigned *tile_cost, unsigned per_tile, const unsigned *tile_bounce)
 {
-   long long i = (long long)blockIdx.x * RT_BLOCK + threadIdx.x;
-   /* tiles without a bounce ray are left to k_resolve (a wave's 64 primaries lie in one tile) */
-   if (tile_bounce && i < n_primary && tile_bounce[(unsigned)i / per_tile] == 0u) return;
-   const bool live = i < n_primary;
-   int node[RT_MAX_RECURSE], stage[RT_MAX_RECURSE];
-   float rx[RT_MAX_RECURSE], ry[RT_MAX_RECURSE], rz[RT_MAX_RECURSE];
-   int sp = live ? 0 : -1;
-   unsigned chain_refl[RT_MAX_RECURSE];
-   unsigned chain = 0;          /* the longest chain of dependent rays below (and with) the node just evaluated, in loop turns of its wave */
-   node[0] = (int)i; stage[0] = 0;
-   F3 ret = mk3(0.0f, 0.0f, 0.0f);
-   if (live) {
-      /* most trees are a single node: the same expression with both children absent, without the stack */
-      float4 rr = *reinterpret_cast<const float4 *>(recs + i);
-      if (__float_as_int(rr.z) < 0 && __float_as_int(rr.w) < 0) {
-         F3 total = mk3(totals[3 * i], totals[3 * i + 1], totals[3 * i + 2]);
-         const F3 none = mk3(0.0f, 0.0f, 0.0f);
-         ret = total * (1.0f - rr.x - rr.y) + rr.x * none + rr.y * none;
-         if (dur) chain = dur[i];
-         sp = -1;
+   /* one workgroup per tile: a tile without a bounce ray is left to k_resolve and costs one look at its flag */
+   if (tile_bounce && tile_bounce[blockIdx.x] == 0u) return;
+   for (long long i = (long long)blockIdx.x * per_tile + threadIdx.x; i < (long long)(blockIdx.x + 1) * per_tile; i += RT_BLOCK) {
+      const bool live = i < n_primary;
+      int node[RT_MAX_RECURSE], stage[RT_MAX_RECURSE];
+      float rx[RT_MAX_RECURSE], ry[RT_MAX_RECURSE], rz[RT_MAX_RECURSE];
+      int sp = live ? 0 : -1;
+      unsigned chain_refl[RT_MAX_RECURSE];
+      unsigned chain = 0;          /* the longest chain of dependent rays below (and with) the node just evaluated, in loop turns of its wave */
+      node[0] = (int)i; stage[0] = 0;
+      F3 ret = mk3(0.0f, 0.0f, 0.0f);
+      if (live) {
+         /* most trees are a single node: the same expression with both children absent, without the stack */
+         float4 rr = *reinterpret_cast<const float4 *>(recs + i);
+         if (__float_as_int(rr.z) < 0 && __float_as_int(rr.w) < 0) {
+            F3 total = mk3(totals[3 * i], totals[3 * i + 1], totals[3 * i + 2]);
+            const F3 none = mk3(0.0f, 0.0f, 0.0f);
+            ret = total * (1.0f - rr.x - rr.y) + rr.x * none + rr.y * none;
+            if (dur) chain = dur[i];
+            sp = -1;
+         }
       }
-   }
-   while (sp >= 0) {
-      float4 rr = *reinterpret_cast<const float4 *>(recs + node[sp]);
-      int child_refl = __float_as_int(rr.z), child_refr = __float_as_int(rr.w);
-      if (stage[sp] == 0) {
-         stage[sp] = 1;
-         if (child_refl >= 0 && sp + 1 < RT_MAX_RECURSE) { sp++; node[sp] = child_refl; stage[sp] = 0; continue; }
-         ret = mk3(0.0f, 0.0f, 0.0f); chain = 0;
+      while (sp >= 0) {
+         float4 rr = *reinterpret_cast<const float4 *>(recs + node[sp]);
+         int child_refl = __float_as_int(rr.z), child_refr = __float_as_int(rr.w);
+         if (stage[sp] == 0) {
+            stage[sp] = 1;
+            if (child_refl >= 0 && sp + 1 < RT_MAX_RECURSE) { sp++; node[sp] = child_refl; stage[sp] = 0; continue; }
+            ret = mk3(0.0f, 0.0f, 0.0f); chain = 0;
+         }
+         if (stage[sp] == 1) {
+            rx[sp] = ret.x; ry[sp] = ret.y; rz[sp] = ret.z; chain_refl[sp] = chain;
+            stage[sp] = 2;
+            if (child_refr >= 0 && sp + 1 < RT_MAX_RECURSE) { sp++; node[sp] = child_refr; stage[sp] = 0; continue; }
+            ret = mk3(0.0f, 0.0f, 0.0f); chain = 0;
+         }
+         long long k = node[sp];
+         F3 total = mk3(totals[3 * k], totals[3 * k + 1], totals[3 * k + 2]);
+         F3 refl = mk3(rx[sp], ry[sp], rz[sp]);
+         ret = total * (1.0f - rr.x - rr.y) + rr.x * refl + rr.y * ret;
+         if (dur) chain = dur[k] + (chain_refl[sp] > chain ? chain_refl[sp] : chain);
+         sp--;
       }
-      if (stage[sp] == 1) {
-         rx[sp] = ret.x; ry[sp] = ret.y; rz[sp] = ret.z; chain_refl[sp] = chain;
-         stage[sp] = 2;
-         if (child_refr >= 0 && sp + 1 < RT_MAX_RECURSE) { sp++; node[sp] = child_refr; stage[sp] = 0; continue; }
-         ret = mk3(0.0f, 0.0f, 0.0f); chain = 0;
-      }
-      long long k = node[sp];
-      F3 total = mk3(totals[3 * k], totals[3 * k + 1], totals[3 * k + 2]);
-      F3 refl = mk3(rx[sp], ry[sp], rz[sp]);
-      ret = total * (1.0f - rr.x - rr.y) + rr.x * refl + rr.y * ret;
-      if (dur) chain = dur[k] + (chain_refl[sp] > chain ? chain_refl[sp] : chain);
-      sp--;
-   }
-   /* rayTrace's clamp (kernel.cu:537-539); NaN passes through clamp unchanged (Util.h:28-30) */
-   if (live) { rgb[3 * i] = clamp01(ret.x); rgb[3 * i + 1] = clamp01(ret.y); rgb[3 * i + 2] = clamp01(ret.z); }
-   if (tile_cost) {
-      /* What this tile costs, for the order in which the next frame starts its tiles: how long its longest chain of
-       * dependent rays was in flight.  A tile started late must be one whose chains are short, or the launch ends on a
-       * few waves finishing them.  A wave's 64 primaries lie in one tile (a tile's sample count is a multiple of 64). */
-      unsigned cost = live ? chain : 0u;
-      unsigned sum = cost;
-      for (int o = 32; o > 0; o >>= 1) { unsigned other = __shfl_xor(cost, o); cost = other > cost ? other : cost; sum += __shfl_xor(sum, o); }
-      if ((threadIdx.x & 63) == 0 && live && cost) {
-         atomicMax(&tile_cost[2 * (unsigned)(i / per_tile)], cost);
-         atomicAdd(&tile_cost[2 * (unsigned)(i / per_tile) + 1], sum);
+      /* rayTrace's clamp (kernel.cu:537-539); NaN passes through clamp unchanged (Util.h:28-30) */
+      if (live) { rgb[3 * i] = clamp01(ret.x); rgb[3 * i + 1] = clamp01(ret.y); rgb[3 * i + 2] = clamp01(ret.z); }
+      if (tile_cost) {
+         /* What this tile costs, for the order in which the next frame starts its tiles: how long its longest chain of
+          * dependent rays was in flight.  A tile started late must be one whose chains are short, or the launch ends on a
+          * few waves finishing them.  A wave's 64 primaries lie in one tile (a tile's sample count is a multiple of 64). */
+         unsigned cost = live ? chain : 0u;
+         unsigned sum = cost;
+         for (int o = 32; o > 0; o >>= 1) { unsigned other = __shfl_xor(cost, o); cost = other > cost ? other : cost; sum += __shfl_xor(sum, o); }
+         if ((threadIdx.x & 63) == 0 && live && cost) {
+            atomicMax(&tile_cost[2 * (unsigned)(i / per_tile)], cost);
+            atomicAdd(&tile_cost[2 * (unsigned)(i / per_tile) + 1], sum);
+         }
       }
    }
 }
@@ -2123,13 +2134,13 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          }
          {
             Timer &tm = ev.begin(S, &st.ms_light);
-            hipLaunchKernelGGL(k_light, dim3(grid_for(cap)), dim3(RT_BLOCK), 0, S, sc, (const QRay *)queue, (const Hit *)hits,
+            hipLaunchKernelGGL(k_light, dim3((unsigned)nb + grid_for((long long)cap - np)), dim3(RT_BLOCK), 0, S, sc, (const QRay *)queue, (const Hit *)hits,
                                (const unsigned *)AT(unsigned, r, o_flags), flag_stride, (const unsigned *)ctr.tail, cap,
                                p->shading, AT(float, r, o_totals), fuse ? (const unsigned *)AT(unsigned, r, o_bounce) : (const unsigned *)nullptr,
                                (unsigned)np, (unsigned)per_tile);
             ev.end(tm, S);
             Timer &tc = ev.begin(S, &st.ms_combine);
-            hipLaunchKernelGGL(k_combine_tree, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, (const SpawnRec *)recs,
+            hipLaunchKernelGGL(k_combine_tree, dim3((unsigned)nb), dim3(RT_BLOCK), 0, S, (const SpawnRec *)recs,
                                (const float *)AT(float, r, o_totals), track_cost ? (const unsigned *)AT(unsigned, r, o_dur) : (const unsigned *)nullptr, np, AT(float, r, o_rgb),
                                track_cost ? s->d_tile_cost : (unsigned *)nullptr, (unsigned)per_tile,
                                fuse ? (const unsigned *)AT(unsigned, r, o_bounce) : (const unsigned *)nullptr);
