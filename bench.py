@@ -22,7 +22,10 @@ complete inside the timed region.
 Objects that ride on the JSON line (rank 0; all but `roofline` and `valu` at N = 1 only):
   roofline      the dominant kernel (the persistent traversal kernel): algorithmic bytes per launch / its average
                 launch duration (HIP events on the stream it runs on), against the ceiling of the memory level
-                that serves those bytes: the XCDs' L2 while scene + BVH fit it, HBM otherwise
+                that serves those bytes: the XCDs' L2 while scene + BVH fit it, HBM otherwise.  Algorithmic bytes =
+                what the reference's own walk of its own tree moves for these rays (per-ray figure from the CPU
+                oracle's counters for this frame) x the rays the launch answers; what the kernel really fetched is
+                reported beside it (`bytes_fetched_per_launch`)
   valu          the same kernel against the vector ALU: wave-instructions per launch (from the committed
                 counter pass of this command) / (SIMDs x issue rate), and the algorithmic flop-equivalents
   cpu_baseline  the CPU oracle (a port of the reference's per-pixel logic) on this box's host cores, same frame
@@ -68,10 +71,29 @@ def frame_size(world, scaling):
     return WIDTH * world, HEIGHT         # any other N: N frames' worth of columns over the same view
 
 
+# What the reference's algorithm does for the headline frame (its own tree, its own walk: kernel.cu:83-200), from the
+# CPU oracle's counters for exactly this frame (bunny 1920x1080, Cook-Torrance, 4 spp, hash jitter, seed 0); the
+# cpu_baseline leg renders the same frame with the oracle and checks them.  Per ray: 33.1 first visits of a node, 10.4
+# revisits after a pop, 0.92 primitive tests, 76.6 box tests.
+REFERENCE_WORK = {"rays": 9315040, "node_first_visits": 307993442, "node_revisits": 97205010, "prim_tests": 8523320,
+                  "box_tests": 713191894}
+
+
+def reference_bytes_per_ray(work=REFERENCE_WORK):
+    """Algorithmic bytes per ray: 64 per node record the reference's walk visits (a revisit after a pop counts again),
+    64 per primitive record it tests, 32 for the ray read and 16 for the result written."""
+    return (64.0 * (work["node_first_visits"] + work["node_revisits"]) + 64.0 * work["prim_tests"]) / work["rays"] + 48.0
+
+
+def reference_flops_per_ray(work=REFERENCE_WORK):
+    """Flop-equivalents per ray of the same walk: 60 per box test (a division counts 6), 90 per primitive test, 40 per ray."""
+    return (60.0 * work["box_tests"] + 90.0 * work["prim_tests"]) / work["rays"] + 40.0
+
+
 def algorithmic_bytes(stats):
-    """Bytes a traversal launch must move for the work it did: 64 per BVH node record visited (both
-    children's boxes + child references, a revisit after a pop counts again), 64 per primitive record
-    tested, 32 per ray read and 16 per result written.  Returns (extend, shadow) for one frame."""
+    """Bytes of the records this library's traversal launch really fetched for a frame: 64 per BVH node record
+    visited, 64 per primitive record tested, 32 per ray and 16 per result.  Less than the reference's walk needs:
+    most rays are answered from a second tree or not walked at all.  Returns (extend, shadow)."""
     n_ext = stats["rays_primary"] + stats["rays_reflect"] + stats["rays_refract"]
     extend = 64 * stats["node_visits"] + 64 * stats["prim_tests"] + (32 + 16) * n_ext
     shadow = 64 * stats["node_visits_shadow"] + 64 * stats["prim_tests_shadow"] + (32 + 16) * stats["rays_shadow"]
@@ -99,7 +121,11 @@ def cpu_baseline(sd, width, height, samples, shading, jitter):
     dt = time.perf_counter() - t0
     c = r["counters"]
     rays = c["rays_primary"] + c["rays_shadow"] + c["rays_reflect"] + c["rays_refract"]
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+    work = {"rays": rays, "node_first_visits": c["node_first_visits"], "node_revisits": c["node_revisits"],
+            "prim_tests": c["prim_tests"], "box_tests": c["box_tests"]}
+    same = (width, height, samples) == (WIDTH, HEIGHT, SAMPLES) and all(int(work[k]) == REFERENCE_WORK[k] for k in REFERENCE_WORK)
+    return {"value": round(rays / dt / 1e6, 3), "reference_work_matches_roofline_constants": bool(same),
+            "reference_work": {k: int(v) for k, v in work.items()}, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "ms_per_frame": round(dt * 1e3, 1),
             "sample": f"one whole {SCENE} {width}x{height} frame at {samples} spp: {rays} rays in {dt:.2f} s wall on {cores} threads "
                       f"({dt * cores:.0f} core-seconds), OpenMP dynamic over rows"}
@@ -300,7 +326,10 @@ def main():
         # one persistent launch traces every ray of the frame (bounce rays and shadow feelers alike)
         launches = max(1, st["launches_trace"])
         avg_ms = acc["ms_trace"] / args.steps / launches
-        bytes_per_launch = (b_extend + b_shadow) / launches
+        # algorithmic bytes: the reference walk's per-ray figure x the rays this launch answers (the oracle counts the
+        # feelers whose own-surface test missed as rays; so does this)
+        rays_answered = cst["rays_total"] + cst["shadow_skipped"]
+        bytes_per_launch = reference_bytes_per_ray() * rays_answered / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         in_l2 = info["device_bytes"] <= L2_BYTES_PER_XCD
         peak = L2_PEAK_GBS if in_l2 else HBM_PEAK_GBS
@@ -315,23 +344,32 @@ def main():
         roofline = {"bound": "hbm", "level": "l2" if in_l2 else "hbm", "kernel": "k_trace<OUT_CHAIN>",
                     "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches,
-                    "bytes_closest_hit_rays": int(b_extend), "bytes_shadow_rays": int(b_shadow),
+                    "bytes_per_ray": round(reference_bytes_per_ray(), 1), "rays_per_launch": int(rays_answered / launches),
+                    "bytes_fetched_per_launch": int((b_extend + b_shadow) / launches),
+                    "bytes_fetched_closest_hit_rays": int(b_extend), "bytes_fetched_shadow_rays": int(b_shadow),
                     "scene_bytes": int(info["device_bytes"]), "hbm_peak": HBM_PEAK_GBS,
-                    "note": ("memory-bound kernel; scene + BVH (%.1f MB) fit each XCD's 4 MiB L2, so the algorithmic bytes (one 64-byte record "
-                             "per node visit) are served by L2 and `peak` is the aggregate L2 bandwidth; `traffic` is the measured "
-                             "HBM-side bytes per launch" % (info["device_bytes"] / 1e6)) if in_l2 else
+                    "note": ("memory-bound kernel; `achieved` = the reference walk's algorithmic bytes (64 per node record it visits and per "
+                             "primitive it tests, 48 per ray: %.0f B/ray from the CPU oracle's counters for this frame) x rays answered / launch "
+                             "time; `bytes_fetched_per_launch` is what this kernel's own counters say it fetched (it proves most answers "
+                             "without the reference's walk); scene + trees (%.1f MB) fit each XCD's 4 MiB L2, so the records are served by L2 "
+                             "and `peak` is the aggregate L2 bandwidth; `traffic` is the measured HBM-side bytes per launch"
+                             % (reference_bytes_per_ray(), info["device_bytes"] / 1e6)) if in_l2 else
                             "scene + BVH exceed the XCDs' L2: `peak` is the HBM bandwidth"}
         insts = profile_counter("pmc_sq", "SQ_INSTS_VALU") if world == 1 else None
-        flops = algorithmic_flops(cst, shading, len(sd.lights)) / launches
+        flops_done = algorithmic_flops(cst, shading, len(sd.lights)) / launches
+        flops = reference_flops_per_ray() * rays_answered / launches
         valu = {"kernel": "k_trace<OUT_CHAIN>", "wave_insts_per_launch": insts,
                 "issue_peak_per_s": SIMDS * VALU_ISSUE_PER_SIMD,
                 "frac": round(insts / (avg_ms * 1e-3) / (SIMDS * VALU_ISSUE_PER_SIMD), 4) if insts else None,
-                "flop_equiv_per_launch": int(flops), "achieved_tflops_equiv": round(flops / (avg_ms * 1e-3) / 1e12, 2),
+                "flop_equiv_per_launch": int(flops), "flop_equiv_done_per_launch": int(flops_done),
+                "achieved_tflops_equiv": round(flops / (avg_ms * 1e-3) / 1e12, 2),
                 "peak_tflops": FP32_PEAK_TFLOPS, "frac_flop_equiv": round(flops / (avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                 "lane_utilisation_node_steps": round((cst["node_visits"] + cst["node_visits_shadow"]) / max(1, 64 * cst["wave_node_steps"]), 3),
                 "lane_utilisation_leaf_steps": round((cst["prim_tests"] + cst["prim_tests_shadow"]) / max(1, 64 * cst["wave_leaf_steps"]), 3),
                 "note": "wave_insts_per_launch = SQ_INSTS_VALU of the committed counter pass of this command (profiles/); "
-                        "issue peak = 1 024 SIMDs x one wave64 instruction per 2 cycles at 2.4 GHz"}
+                        "issue peak = 1 024 SIMDs x one wave64 instruction per 2 cycles at 2.4 GHz; flop_equiv_per_launch = the "
+                        "reference walk's flop-equivalents (60 per box test, 90 per primitive test, 40 per ray, from the oracle's "
+                        "counters) x rays answered, flop_equiv_done_per_launch = the same formula on this kernel's own counts"}
         if world == 1 and not args.no_cpu_baseline:
             baseline = cpu_baseline(sd, width, height, SAMPLES, shading, jitter)
         if world == 1 and not args.no_secondary:
