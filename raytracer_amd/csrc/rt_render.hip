@@ -395,7 +395,7 @@ struct TraceArgs {
    QRay *rays;                  /* the queue; OUT_CHAIN appends spawned rays behind the first n */
    unsigned long long n;        /* rays to fetch (OUT_CHAIN: the primaries) */
    Hit *hits;
-   unsigned *flag_words;        /* OUT_CHAIN: isInShadow of (queue entry i, light k) is bit k%32 of flag_words[i*flag_stride + k/32]; zeroed */
+   unsigned *flag_words;        /* OUT_CHAIN: isInShadow of (queue entry i, light k) is bit k%32 of flag_words[i*flag_stride + k/32]; cleared when entry i is shaded */
    unsigned flag_stride;
    unsigned long long *next;    /* this launch's zeroed fetch counters: RT_FETCH_STREAMS of them, 64 bytes apart */
    unsigned long long *stats;
@@ -414,7 +414,7 @@ struct TraceArgs {
    unsigned list_cap;
    const int *tile_order;       /* when non-null: the order in which the launch's tiles are started (costliest first) */
    StackEntry *spill;           /* SPILL kernels: stack entries beyond the RT_LDS_STACK kept in LDS, [entry - RT_LDS_STACK][lane of the launch] */
-   unsigned *dur;               /* when non-null: per queue entry, how many turns of its wave's loop the closest-hit ray was in flight */
+   unsigned *dur;               /* when non-null: per queue entry, what the closest-hit ray cost: its own node steps + 4 x its leaf steps */
    unsigned *tile_bounce;       /* when non-null: per tile of the launch (zeroed), set when a primary of the tile spawns a bounce ray */
 };
 
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
 #endif
 
    unsigned long long guard = 0;       /* wave-uniform: turns of the loop below */
-   unsigned born = 0;                  /* the turn in which this lane's ray started */
+   unsigned born = 0;                  /* node and leaf steps this lane's ray has taken: what it cost, whatever else the wave was doing */
    bool active = false;
    bool pend = false;                  /* OUT_CHAIN: finished, its bounce rays not spawned yet */
    bool exhausted = n == 0;            /* wave-uniform: the queue has no more rays to fetch */
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       } else {
          Hit h; h.prim = closest; h.t = t; a.hits[idx] = h;
          if (OUT == OUT_CHAIN) {
-            if (a.dur) a.dur[idx] = (unsigned)guard - born;
+            if (a.dur) a.dur[idx] = born;
             if (closest >= 0) {
                pend = true;
                if (tag == 1) store_qray(a.rays, idx, c.r.o, c.r.d, -FLT_MAX, 1);      /* a primary: made on fetch, not stored then (bounce rays are, when they are spawned) */
@@ -662,6 +662,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       int2 ch; ch.x = tail.x; ch.y = tail.y;
       StackEntry top = peek();
       if (COUNT) { if (OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND) nvs++; else nv++; }
+      born++;
       float left, right;
       if (VARIANT == 2) {
          left = slab_literal(c.r, na.x, na.y, na.z, na.w, nb.x, nb.y);
@@ -769,6 +770,10 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                /* the shaded point (kernel.cu:340) and its primitive, once, for the feelers of all its lights */
                F3 P = ray_point(c.r, t);
                a.points[idx] = make_float4(P.x, P.y, P.z, __int_as_float(closest));
+               /* ... and its shadow bits start clear (only entries that are shaded have bits anyone reads, so they are
+                * cleared here rather than all at once before the launch; the feelers that set them start in later
+                * refills, behind the fence of a refill that takes list entries) */
+               for (unsigned w = 0; w < a.flag_stride; w++) a.flag_words[(size_t)idx * a.flag_stride + w] = 0u;
             }
             const unsigned cnt = cR + cT;
             if (cnt > res_hi - res_lo && !res_full) {
@@ -827,7 +832,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          if (!sc.fast_ok) c.fast = false;
          toBeat = -FLT_MAX; idx = (unsigned)(cont_refl ? out.child_refl : out.child_refr); tag = tag + 1; mode = MODE_EXTEND;
          t = FLT_MAX; closest = -1; sp = 0; enter_tree();
-         active = true; ray_steps = 0; born = (unsigned)guard;
+         active = true; ray_steps = 0; born = 0;
          if (cur == RT_ROOT_EMPTY) finish(false);
       }
       return front_pushed;
@@ -920,7 +925,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                c = make_ctx(feeler);
                if (!sc.fast_ok) c.fast = false;
                tag = (int)k; idx = node;
-               t = FLT_MAX; closest = -1; sp = 0; ray_steps = 0; born = (unsigned)guard;
+               t = FLT_MAX; closest = -1; sp = 0; ray_steps = 0; born = 0;
                if (hprim >= sc.n_prims) {
                   /* planes are not in the tree: their own-surface test is done here */
                   float param = plane_intersect(sc, hprim - sc.n_prims, feeler);   /* kernel.cu:351 */
@@ -978,7 +983,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                      if (!sc.fast_ok) c.fast = false;
                      toBeat = q.to_beat; idx = (unsigned)my; tag = q.valid; mode = MODE_EXTEND;
                      t = FLT_MAX; closest = -1; sp = 0; enter_tree();
-                     active = true; ray_steps = 0; born = (unsigned)guard;
+                     active = true; ray_steps = 0; born = 0;
                      if (cur == RT_ROOT_EMPTY) finish(false);
                   }
                }
@@ -1035,6 +1040,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          float leaf_dist = 0.0f;
          StackEntry top; top.child = 0; top.dist = 0.0f;
          if (at_leaf) {
+            born += 4;                   /* a leaf step weighs about as much as a few node steps */
             top = peek();
             float dist = 0.0f;
             if (!(OUT == OUT_CHAIN && (mode & MODE_VERIFY))) dist = prim_intersect(sc, ~cur, c.r);
@@ -1270,11 +1276,12 @@ __device__ __forceinline__ ShadePoint shade_point(const DScene &sc, const QRay *
 /* start of a chunk: its counters to zero, the queue's tail behind the primaries, and (first chunk) the statistics;
  * one launch instead of a memset each */
 __global__ __launch_bounds__(RT_BLOCK) void k_begin_chunk(unsigned long long *stats, int n_stats, unsigned long long *ctr, unsigned *tail,
-                                                          unsigned n_primary, unsigned *tile_cost, int n_cost)
+                                                          unsigned n_primary, unsigned *tile_cost, int n_cost, unsigned *tile_bounce, int n_bounce)
 {
    int i = (int)(blockIdx.x * RT_BLOCK + threadIdx.x);
    if (stats && i < n_stats) stats[i] = 0ULL;
    if (tile_cost && i < n_cost) tile_cost[i] = 0u;
+   if (tile_bounce && i < n_bounce) tile_bounce[i] = 0u;
    if (i < 8 * (int)RT_FETCH_STREAMS) ctr[i] = 0ULL;       /* the fetch counters; the tail's words follow them */
    if (i == 0) *tail = n_primary;
 }
@@ -1346,7 +1353,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs,
       float rx[RT_MAX_RECURSE], ry[RT_MAX_RECURSE], rz[RT_MAX_RECURSE];
       int sp = live ? 0 : -1;
       unsigned chain_refl[RT_MAX_RECURSE];
-      unsigned chain = 0;          /* the longest chain of dependent rays below (and with) the node just evaluated, in loop turns of its wave */
+      unsigned chain = 0;          /* the longest chain of dependent rays below (and with) the node just evaluated, in traversal steps of its rays */
       node[0] = (int)i; stage[0] = 0;
       F3 ret = mk3(0.0f, 0.0f, 0.0f);
       if (live) {
@@ -1385,7 +1392,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs,
       if (live) { rgb[3 * i] = clamp01(ret.x); rgb[3 * i + 1] = clamp01(ret.y); rgb[3 * i + 2] = clamp01(ret.z); }
       if (tile_cost) {
          /* What this tile costs, for the order in which the next frame starts its tiles: how long its longest chain of
-          * dependent rays was in flight.  A tile started late must be one whose chains are short, or the launch ends on a
+          * dependent rays was (in traversal steps: a figure that does not depend on how the waves were scheduled, so a
+          * still camera gets the same order frame after frame).  A tile started late must be one whose chains are short, or the launch ends on a
           * few waves finishing them.  A wave's 64 primaries lie in one tile (a tile's sample count is a multiple of 64). */
          unsigned cost = live ? chain : 0u;
          unsigned sum = cost;
@@ -2101,13 +2109,14 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          {
             /* counters to zero, spawned rays appended behind the primaries, tile costs and (first chunk) statistics cleared */
             const int n_stats = c == 0 ? ST_COUNT * RT_STAT_REPL : 0, n_cost = track_cost ? 2 * (int)n_sel : 0;
-            const int n_init = n_stats > n_cost ? (n_stats > RT_CTR_WORDS ? n_stats : RT_CTR_WORDS) : (n_cost > RT_CTR_WORDS ? n_cost : RT_CTR_WORDS);
+            int n_init = n_stats > n_cost ? (n_stats > RT_CTR_WORDS ? n_stats : RT_CTR_WORDS) : (n_cost > RT_CTR_WORDS ? n_cost : RT_CTR_WORDS);
+            if (fuse && (int)nb > n_init) n_init = (int)nb;
             hipLaunchKernelGGL(k_begin_chunk, dim3(grid_for(n_init)), dim3(RT_BLOCK), 0, S, c == 0 ? s->d_stats : (unsigned long long *)nullptr,
-                               n_stats, s->d_ctr, ctr.tail, (unsigned)np, track_cost ? s->d_tile_cost : (unsigned *)nullptr, n_cost);
+                               n_stats, s->d_ctr, ctr.tail, (unsigned)np, track_cost ? s->d_tile_cost : (unsigned *)nullptr, n_cost,
+                               fuse ? AT(unsigned, r, o_bounce) : (unsigned *)nullptr, (int)nb);
             TraceArgs a; memset(&a, 0, sizeof a);
             a.rays = queue; a.n = (unsigned long long)np; a.hits = hits; a.next = ctr.next_chain;
             a.flag_words = AT(unsigned, r, o_flags); a.flag_stride = flag_stride;
-            if (L > 0) HIP_TRY(hipMemsetAsync(a.flag_words, 0, flag_bytes, S));
             a.recs = recs; a.tail = ctr.tail; a.cap = cap; a.max_rec = max_rec; a.cam = cam; a.g = g;
             a.points = AT(float4, r, o_points);
             a.lists = s->d_lists; a.list_cap = s->list_cap;
@@ -2120,10 +2129,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
                a.tile_order = s->d_tile_order;
             }
             if (track_cost) a.dur = AT(unsigned, r, o_dur);
-            if (fuse) {
-               a.tile_bounce = AT(unsigned, r, o_bounce);
-               HIP_TRY(hipMemsetAsync(a.tile_bounce, 0, sizeof(unsigned) * (size_t)nb, S));
-            }
+            if (fuse) a.tile_bounce = AT(unsigned, r, o_bounce);
             Timer &tm = ev.begin(S, &st.ms_trace);
             launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, S);
             ev.end(tm, S); st.launches_trace++;
