@@ -1563,6 +1563,7 @@ struct rt_scene {
    bool streams_ok;
    std::vector<hipEvent_t> timing_events;   /* spare events of the per-frame timers */
    std::vector<int32_t> prim_ids_host;      /* host copy of DScene::prim_ids */
+   std::vector<unsigned> last_cost;         /* the tile costs the current start order was made from */
    /* launch shape and tuning of the traversal kernel, read once per scene from its device and the environment */
    int trace_blocks;        /* workgroups of a full traversal launch: what the device holds at 4 waves per SIMD */
    int refill_idle, node_burst, leaf_trigger, use_tile_order, order_classes;
@@ -2195,7 +2196,13 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          continue;                              /* some bounce rays were dropped: render the frame again */
       }
       if (max_rec > 1 && wanted * 1.1 > F) s->node_factor = (float)(wanted * 1.25 < 64.0 ? wanted * 1.25 : 64.0);
-      if (track_cost) {
+      /* (the costs are the rays' own step counts: a still camera brings the same ones back every frame, and then the
+       * order stands as it is) */
+      const bool same_costs = track_cost && s->order_valid && memcmp(key, s->order_key, sizeof key) == 0 && !s->last_cost.empty() &&
+                              s->last_cost.size() == 2 * (size_t)n_sel &&
+                              memcmp(s->last_cost.data(), s->h_tile_cost, 2 * sizeof(unsigned) * (size_t)n_sel) == 0;
+      if (track_cost && !same_costs) {
+         s->last_cost.assign(s->h_tile_cost, s->h_tile_cost + 2 * (size_t)n_sel);
          /* Costliest first, in a few classes of equal size (by rank of the tile's longest chain); tiles of a class stay
           * in image order, so neighbouring waves still work on neighbouring tiles: a scattered order costs more in the
           * caches than the shorter tail wins. */
@@ -2209,7 +2216,12 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          std::sort(sorted.begin(), sorted.end(), std::greater<unsigned>());
          std::vector<unsigned> bound((size_t)classes);        /* class c holds costs above bound[c] (and not in an earlier class) */
          for (int c = 0; c < classes; c++) { long long at = (long long)(c + 1) * n_sel / classes; bound[(size_t)c] = at < n_sel ? sorted[(size_t)at] : 0u; }
-         auto cls = [&](unsigned cost) { int c = 0; while (c + 1 < classes && cost <= bound[(size_t)c]) c++; return c; };
+         /* bound[] falls with the class number: the class of a cost is the number of bounds it does not exceed */
+         auto cls = [&](unsigned cost) {
+            int lo_c = 0, hi_c = classes - 1;           /* the first c in [0, classes - 1) with cost > bound[c], else classes - 1 */
+            while (lo_c < hi_c) { int mid = (lo_c + hi_c) / 2; if (cost > bound[(size_t)mid]) hi_c = mid; else lo_c = mid + 1; }
+            return lo_c;
+         };
          std::vector<long long> start((size_t)classes + 1, 0);
          for (long long k = 0; k < n_sel; k++) start[(size_t)cls(costs[(size_t)k]) + 1]++;
          for (int c = 0; c < classes; c++) start[(size_t)c + 1] += start[(size_t)c];
