@@ -170,7 +170,7 @@ typedef struct rt_stats {
    /* shares of the waves' lifetime spent in refills (spawning bounce rays, starting new rays), in node steps and
     * in leaf steps */
    float wave_time_refill, wave_time_node, wave_time_leaf;
-   int32_t pad0;
+   int32_t second_tree;         /* which rays of this frame started in the second tree: bit 0 closest-hit rays, bit 1 shadow feelers */
    /* the longest single ray, in wave steps it was in flight */
    uint64_t max_ray_steps;
    /* most spawned rays / shadow items any wave held back at once (always filled); a frame that overflows the

@@ -94,7 +94,7 @@ class Stats(C.Structure):
                 ("node_visits_shadow", C.c_uint64), ("prim_tests_shadow", C.c_uint64), ("tie_events_shadow", C.c_uint64),
                 ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64),
                 ("lane_steps_at_leaf", C.c_uint64), ("lane_steps_no_ray", C.c_uint64), ("wave_refills", C.c_uint64),
-                ("wave_time_refill", C.c_float), ("wave_time_node", C.c_float), ("wave_time_leaf", C.c_float), ("pad0", C.c_int32),
+                ("wave_time_refill", C.c_float), ("wave_time_node", C.c_float), ("wave_time_leaf", C.c_float), ("second_tree", C.c_int32),
                 ("max_ray_steps", C.c_uint64), ("max_spawn_list", C.c_uint64),
                 ("hits_certified", C.c_uint64), ("hits_contested", C.c_uint64), ("hits_unreached", C.c_uint64)]
 

@@ -60,7 +60,8 @@ struct DScene {
    const int *prim_ids;     /* primitive id (the caller's numbering) of device primitive k; see rt_scene_create */
    const int *leaf_parent;  /* scenes with a miss filter: the node of the reference's tree whose child device primitive k is */
    int n_prims, n_planes, n_lights, root;
-   int filter_root;  /* node index of the miss filter's root, or RT_ROOT_EMPTY when the scene has none */
+   int filter_root;  /* node index of the second tree's root, or RT_ROOT_EMPTY when the scene has none (or the launch uses none) */
+   int filter_kinds; /* which rays of this launch start in the second tree: bit 0 closest-hit rays, bit 1 shadow feelers */
    int fast_ok;      /* every BVH bound is finite and below 2^40 in magnitude */
    int any_xform;    /* some BVH primitive carries a transform */
 };
@@ -721,7 +722,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
     *    from its root, unchanged.
     * Rays outside the short box test's range do not use the second tree. */
    auto enter_tree = [&]() {
-      if (sc.filter_root != RT_ROOT_EMPTY && c.fast && !wave_lit) {
+      const int kind_bit = (mode & MODE_KIND) == MODE_EXTEND ? 1 : 2;
+      if (sc.filter_root != RT_ROOT_EMPTY && (sc.filter_kinds & kind_bit) && c.fast && !wave_lit) {
          cur = sc.filter_root; mode |= MODE_FILTER;
          if (OUT == OUT_CHAIN) {
             if ((mode & MODE_KIND) == MODE_EXTEND) toBeat = FLT_MAX;      /* the nearest of the other primitives, so far */
@@ -1570,6 +1572,14 @@ struct rt_scene {
    double order_mean_weight;
    unsigned reserve;        /* queue entries a wave reserves at a time for its bounce rays */
    int fuse_resolve;        /* tiles without bounce rays are shaded by k_resolve itself */
+   /* Which rays start in the second tree is tried out per scene and frame size: frames are the same bytes either way,
+    * so the first frames of a size go through the four combinations (closest-hit rays x feelers) and the quickest stays.
+    * Scenes whose rays mostly hit something they cannot be certified for (rays inside glass) do better without. */
+   int filter_auto;         /* 1: try out; 0: always as filter_choice says (RT_MISS_FILTER=1) */
+   int filter_choice;       /* bits as DScene::filter_kinds */
+   int probe_step;          /* frames of the current size rendered so far, up to the end of the try-out */
+   long long probe_key[4];
+   float probe_ms[4];
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1753,6 +1763,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->d.root = (h.root < 0 && h.root != RT_ROOT_EMPTY) ? ~pos_of[(size_t)~h.root] : h.root;
    s->d.fast_ok = h.bounds_in_range;
    s->d.filter_root = (n_filter > 0 && h.root >= 0) ? (int)n_tree : RT_ROOT_EMPTY;
+   s->d.filter_kinds = 3;
    s->d.any_xform = h.any_xform;
 
    if (hipMalloc((void **)&s->d_ctr, RT_CTR_WORDS * sizeof(unsigned long long)) != hipSuccess ||
@@ -1930,6 +1941,12 @@ static void scene_tuning(rt_scene *s)
    s->order_classes = env_int("RT_ORDER_CLASSES", RT_ORDER_CLASSES, false);
    s->order_mean_weight = (double)env_int("RT_ORDER_MEAN_WEIGHT", RT_ORDER_MEAN_WEIGHT, true);
    s->fuse_resolve = env_int("RT_FUSE_RESOLVE", 1, true);
+   {
+      const char *e = getenv("RT_MISS_FILTER");
+      s->filter_auto = !(e && *e && atoi(e) == 1 && e[0] == '1');      /* "1": always; unset / "auto": try out ("0" builds no second tree at all) */
+      s->filter_choice = 3; s->probe_step = 0;
+      memset(s->probe_key, 0, sizeof s->probe_key);
+   }
    int r = env_int("RT_RESERVE", RT_RESERVE, false);
    s->reserve = (unsigned)(r < 128 ? 128 : r);      /* one spawn stage can ask for 128 entries */
 }
@@ -1947,8 +1964,11 @@ static int ensure_lists(rt_scene *s)
 }
 
 static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs a, unsigned long long n_hint, size_t lds_bytes,
-                         hipStream_t stream)
+                         hipStream_t stream, int filter_kinds = 3)
 {
+   DScene d = s->d;
+   d.filter_kinds = filter_kinds;
+   if (!filter_kinds) d.filter_root = RT_ROOT_EMPTY;
    unsigned long long want = (n_hint + RT_BLOCK - 1) / RT_BLOCK;
    unsigned blocks = (unsigned)(want < (unsigned long long)s->trace_blocks ? want : (unsigned long long)s->trace_blocks);
    if (blocks == 0) return;
@@ -1957,8 +1977,8 @@ static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs 
    if (!a.stats) a.stats = s->d_stats;
    a.spill = s->d_spill;
    const bool spill = stack_depth(s) > RT_LDS_STACK;
-#define RT_LAUNCH_TRACE(O, C) do { if (spill) hipLaunchKernelGGL((k_trace<O, C, true>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, a); \
-                                   else hipLaunchKernelGGL((k_trace<O, C, false>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, s->d, a); } while (0)
+#define RT_LAUNCH_TRACE(O, C) do { if (spill) hipLaunchKernelGGL((k_trace<O, C, true>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, d, a); \
+                                   else hipLaunchKernelGGL((k_trace<O, C, false>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, d, a); } while (0)
    if (out_mode == OUT_CHAIN) { if (count) RT_LAUNCH_TRACE(OUT_CHAIN, true); else RT_LAUNCH_TRACE(OUT_CHAIN, false); }
    else { if (count) RT_LAUNCH_TRACE(OUT_HIT, true); else RT_LAUNCH_TRACE(OUT_HIT, false); }
 #undef RT_LAUNCH_TRACE
@@ -2027,6 +2047,16 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    size_t lds_bytes = 0;
    { int rc = trace_lds_bytes(s, &lds_bytes); if (rc != RT_OK) return rc; }
    hipStream_t M = s->chain;
+
+   /* which rays start in the second tree this frame: the scene's choice, or the next combination of the try-out */
+   int filter_kinds = s->filter_choice;
+   const long long probe_key[4] = {p->width, p->height, p->sample_count, (long long)tile_first * 65536 + tile_stride};
+   const bool probing = s->filter_auto && view == VIEW_FRAME && sc.filter_root != RT_ROOT_EMPTY;
+   if (probing) {
+      if (memcmp(probe_key, s->probe_key, sizeof probe_key) != 0) { memcpy(s->probe_key, probe_key, sizeof probe_key); s->probe_step = 0; s->filter_choice = 3; }
+      static const int order[5] = {3, 3, 1, 2, 0};        /* the first frame of a size is not timed: it has no tile order yet */
+      filter_kinds = s->probe_step < 5 ? order[s->probe_step] : s->filter_choice;
+   }
 
    int attempts = 0;
    for (int attempt = 0;; attempt++) {
@@ -2132,7 +2162,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             if (track_cost) a.dur = AT(unsigned, r, o_dur);
             if (fuse) a.tile_bounce = AT(unsigned, r, o_bounce);
             Timer &tm = ev.begin(S, &st.ms_trace);
-            launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, S);
+            launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, S, filter_kinds);
             ev.end(tm, S); st.launches_trace++;
          }
          if (view == VIEW_PRIMARY) {
@@ -2272,6 +2302,16 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       st.wave_time_node = w > 0 ? (float)((double)sum_stat(s->h_stats, ST_CLK_NODE) / w) : 0.0f;
       st.wave_time_leaf = w > 0 ? (float)((double)sum_stat(s->h_stats, ST_CLK_LEAF) / w) : 0.0f;
    }
+   if (probing && s->probe_step < 5) {
+      if (s->probe_step >= 1) s->probe_ms[filter_kinds] = st.ms_trace;
+      if (++s->probe_step == 5) {
+         /* the quickest stays; anything but "both" has to win by more than the frame-to-frame noise */
+         int best = 3;
+         for (int k = 0; k < 3; k++) if (s->probe_ms[k] < 0.96f * s->probe_ms[3] && s->probe_ms[k] < s->probe_ms[best]) best = k;
+         s->filter_choice = best;
+      }
+   }
+   st.second_tree = filter_kinds;
    st.max_ray_steps = s->h_stats[ST_MAX_RAY_STEPS * RT_STAT_REPL];
    st.max_spawn_list = s->h_stats[ST_MAX_LIST * RT_STAT_REPL];
    st.attempts = attempts;
