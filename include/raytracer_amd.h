@@ -216,6 +216,8 @@ enum {
    RT_SCENE_NO_FILTER = 8,   /* do not build the miss filter (a second, widened tree that only serves to prove that a ray
                               * meets no primitive, so that the reference's tree need not be walked for it); results are
                               * the same with and without it */
+   RT_SCENE_FILTER_ALWAYS = 16,  /* closest-hit rays and shadow feelers always start in the second tree (default: the first
+                              * frames of a size try out who should, and the quickest combination stays) */
    RT_SCENE_GPU_BVH = 4      /* NOT the reference's tree either: a linear BVH (Morton codes + radix tree) built on the
                               * device in milliseconds; same caveat as RT_SCENE_FAST_BVH, lower tree quality, for scenes
                               * that change every frame.  Ignored by rt_scene_create_host */

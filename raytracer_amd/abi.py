@@ -31,7 +31,7 @@ RT_OUT_FRAME, RT_OUT_TILES = 0, 1
 RT_TILE = 32
 RT_MAX_RECURSE = 6
 RT_TRACE_RAYS_STATIC_MAX = 524288
-RT_SCENE_DEFAULT, RT_SCENE_COUNTERS, RT_SCENE_FAST_BVH, RT_SCENE_GPU_BVH, RT_SCENE_NO_FILTER = 0, 1, 2, 4, 8
+RT_SCENE_DEFAULT, RT_SCENE_COUNTERS, RT_SCENE_FAST_BVH, RT_SCENE_GPU_BVH, RT_SCENE_NO_FILTER, RT_SCENE_FILTER_ALWAYS = 0, 1, 2, 4, 8, 16
 
 f32, i32 = np.float32, np.int32
 

@@ -73,7 +73,7 @@ def make_params(width, height, sample_count=1, shading=PHONG, jitter=abi.RT_JITT
 class Scene:
     """Device-resident scene: objects in the reference's creation order, its BVH, flattened (rt_scene_create)."""
 
-    def __init__(self, data: SceneData, device=0, counters=False, host_only=False, fast_bvh=False, gpu_bvh=False, miss_filter=True):
+    def __init__(self, data: SceneData, device=0, counters=False, host_only=False, fast_bvh=False, gpu_bvh=False, miss_filter=None):
         self._lib = abi.load_library()
         self.data = data
         desc, keep = data.to_desc()
@@ -83,7 +83,7 @@ class Scene:
         else:
             _check(self._lib, self._lib.rt_scene_create(C.byref(desc), device,
                                                         (abi.RT_SCENE_COUNTERS if counters else 0) | (abi.RT_SCENE_FAST_BVH if fast_bvh else 0)
-                                                        | (abi.RT_SCENE_GPU_BVH if gpu_bvh else 0) | (0 if miss_filter else abi.RT_SCENE_NO_FILTER),
+                                                        | (abi.RT_SCENE_GPU_BVH if gpu_bvh else 0) | (0 if miss_filter is None else abi.RT_SCENE_FILTER_ALWAYS if miss_filter else abi.RT_SCENE_NO_FILTER),
                                                         C.byref(h)))
         self._h = h
         self.device = device

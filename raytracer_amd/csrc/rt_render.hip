@@ -1764,6 +1764,14 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->d.fast_ok = h.bounds_in_range;
    s->d.filter_root = (n_filter > 0 && h.root >= 0) ? (int)n_tree : RT_ROOT_EMPTY;
    s->d.filter_kinds = 3;
+   {
+      /* the first guess, for the frames before the try-out has spoken (a cold launch_kernel call renders only one):
+       * a scene made mostly of glass does better without the second tree */
+      long long glass = 0;
+      for (int k = 0; k < h.n_prims; k++) if (h.materials[h.prims[k].material].refr > 0.0f) glass++;
+      if (flags & RT_SCENE_FILTER_ALWAYS) { s->filter_auto = 0; s->filter_choice = 3; }
+      if (s->filter_auto && h.n_prims > 0 && glass * 4 > (long long)h.n_prims) s->filter_choice = 0;
+   }
    s->d.any_xform = h.any_xform;
 
    if (hipMalloc((void **)&s->d_ctr, RT_CTR_WORDS * sizeof(unsigned long long)) != hipSuccess ||
@@ -2053,9 +2061,9 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    const long long probe_key[4] = {p->width, p->height, p->sample_count, (long long)tile_first * 65536 + tile_stride};
    const bool probing = s->filter_auto && view == VIEW_FRAME && sc.filter_root != RT_ROOT_EMPTY;
    if (probing) {
-      if (memcmp(probe_key, s->probe_key, sizeof probe_key) != 0) { memcpy(s->probe_key, probe_key, sizeof probe_key); s->probe_step = 0; s->filter_choice = 3; }
-      static const int order[5] = {3, 3, 1, 2, 0};        /* the first frame of a size is not timed: it has no tile order yet */
-      filter_kinds = s->probe_step < 5 ? order[s->probe_step] : s->filter_choice;
+      if (memcmp(probe_key, s->probe_key, sizeof probe_key) != 0) { memcpy(s->probe_key, probe_key, sizeof probe_key); s->probe_step = 0; }
+      static const int order[5] = {-1, 3, 1, 2, 0};       /* the first frame of a size is not timed (it has no tile order yet): it runs on the current choice */
+      filter_kinds = s->probe_step < 5 && order[s->probe_step] >= 0 ? order[s->probe_step] : s->filter_choice;
    }
 
    int attempts = 0;
