@@ -7,7 +7,7 @@ OUT=gpurun_out/prof_${TAG}_balls2
 REPO=$(pwd)
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 $REPO/tests/gpu_breakdown.py balls2"
+CMD="python3 $REPO/tools/gpu_breakdown.py balls2"
 cd /tmp
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/kt -o kt -- $CMD > $REPO/$OUT/kt.log 2>&1
 timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $REPO/$OUT/pmc_sq -o pmc -- $CMD > $REPO/$OUT/pmc_sq.log 2>&1

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as ra
 from raytracer_amd import abi
 
-G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes")
+G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "scenes")
 CASES = (("bunny", 4, abi.RT_COOK_TORRANCE), ("bunny_obj", 4, abi.RT_COOK_TORRANCE), ("balls2", 1, abi.RT_PHONG),
          ("dragon_large_tris", 1, abi.RT_PHONG), ("iceBot", 1, abi.RT_PHONG))
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 14

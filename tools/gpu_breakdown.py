@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as ra
 from raytracer_amd import abi
 
-G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes")
+G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "scenes")
 
 CASES = {
     "bunny": ("bunny", 1920, 1080, 4, abi.RT_COOK_TORRANCE),

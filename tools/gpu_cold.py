@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as ra
 from raytracer_amd import abi
-G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes")
+G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "scenes")
 for name in ("balls2", "dragon_large_tris", "bunny"):
     sd = ra.SceneData.load(os.path.join(G, name + ".npz"))
     for rep in range(3):

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as ra
 from raytracer_amd import abi, synth
 
-G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes")
+G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "scenes")
 
 
 def run(label, sd, w, h, spp, shading, fast=False, frames=8):

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as ra
 from raytracer_amd import abi
-G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes")
+G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "scenes")
 name = sys.argv[1] if len(sys.argv) > 1 else "balls2"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 sd = ra.SceneData.load(os.path.join(G, name + ".npz"))

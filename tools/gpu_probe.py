@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as ra
 from raytracer_amd import abi
-G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes")
+G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "scenes")
 for name, spp, sh in (("balls2", 1, abi.RT_PHONG), ("bunny", 4, abi.RT_COOK_TORRANCE), ("dragon_large_tris", 1, abi.RT_PHONG), ("iceBot", 1, abi.RT_PHONG)):
     sd = ra.SceneData.load(os.path.join(G, name + ".npz"))
     for filt in (True, False):

@@ -3,7 +3,7 @@ import itertools, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as ra
 from raytracer_amd import abi
-G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes")
+G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "scenes")
 CASES = (("bunny", 4, abi.RT_COOK_TORRANCE), ("balls2", 1, abi.RT_PHONG), ("dragon_large_tris", 1, abi.RT_PHONG))
 scenes = {n: ra.SceneData.load(os.path.join(G, n + ".npz")) for n, _, _ in CASES}
 grid = {"RT_LEAF_TRIGGER": (16, 24, 32), "RT_NODE_BURST": (6, 8, 12), "RT_REFILL_IDLE": (14, 20, 28)}
