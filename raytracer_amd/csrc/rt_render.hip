@@ -387,11 +387,15 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2, MODE_KIND = 3,
 #define RT_LEAF_TRIGGER 24  /* lanes waiting at a leaf that end a burst of node steps early */
 #define RT_FETCH_STREAMS 64u /* counters the primaries are handed out through */
 #define RT_CTR_WORDS (8 * ((int)RT_FETCH_STREAMS + 1))   /* 64-bit words of a launch's counters: the streams' (64 bytes apart), then the queue tail */
-#define RT_ORDER_CLASSES 64 /* classes of tile cost that decide the order in which a frame's tiles are started */
+#define RT_ORDER_CLASSES 256 /* classes of tile cost that decide the order in which a frame's tiles are started */
 #define RT_ORDER_MEAN_WEIGHT 4
 #define RT_LDS_STACK 16     /* stack entries per lane kept in LDS; deeper trees spill the rest to global memory */
 #define RT_RESERVE 256      /* queue entries a wave reserves at a time for the bounce rays it spawns */
 
+#ifdef RT_DEBUG_WAVES
+__device__ unsigned long long dbg_waves[4096 * 8];
+extern "C" int rt_debug_read_waves(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dbg_waves), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : 1; }
+#endif
 struct TraceArgs {
    QRay *rays;                  /* the queue; OUT_CHAIN appends spawned rays behind the first n */
    unsigned long long n;        /* rays to fetch (OUT_CHAIN: the primaries) */
@@ -542,6 +546,10 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    const unsigned long long clock_start = COUNT ? wall_clock64() : 0ULL;     /* 100 MHz */
 #ifdef RT_DEBUG_EXIT_HIST
    const unsigned long long dbg_start = wall_clock64();
+#endif
+#ifdef RT_DEBUG_WAVES
+   const unsigned long long dbg_t0 = wall_clock64();
+   unsigned long long dbg_last_fetch = 0, dbg_last_spawn = 0, dbg_list_at_dry = ~0ULL; unsigned dbg_fetched = 0, dbg_refills = 0;
 #endif
 
    unsigned long long guard = 0;       /* wave-uniform: turns of the loop below */
@@ -885,6 +893,12 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
 #ifdef RT_DEBUG_REFILL_CLK
          const unsigned long long clkA = wall_clock64();
 #endif
+#ifdef RT_DEBUG_WAVES
+         dbg_refills++;
+         if (any_pend) dbg_last_spawn = wall_clock64();
+         if (exhausted && dbg_list_at_dry == ~0ULL) dbg_list_at_dry = (unsigned long long)list_count;
+         if (need > 0) { dbg_last_fetch = wall_clock64(); dbg_fetched += (unsigned)need; }
+#endif
          if (need > 0) {
             q_base = __shfl(q_raw, 0);
 #ifdef RT_DEBUG_REFILL_CLK
@@ -1109,6 +1123,13 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       }
       if (COUNT) clk_leaf += wall_clock64() - clk2;
    }
+#ifdef RT_DEBUG_WAVES
+   if (lane == 0) {
+      unsigned long long *w = dbg_waves + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+      w[0] = dbg_t0; w[1] = dbg_last_fetch; w[2] = wall_clock64(); w[3] = (unsigned long long)list_peak; w[4] = dbg_fetched; w[5] = dbg_refills;
+      w[6] = dbg_last_spawn; w[7] = dbg_list_at_dry;
+   }
+#endif
 #ifdef RT_DEBUG_EXIT_HIST
    if (lane == 0) {
       unsigned long long dt = wall_clock64() - dbg_start;
