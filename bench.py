@@ -132,12 +132,13 @@ def cpu_baseline(sd, width, height, samples, shading, jitter):
 
 
 def profile_counter(pas, counter):
-    """Per-launch value of a counter of the dominant kernel from the committed counter passes of this command."""
+    """Per-launch value of a counter of the dominant kernel from the committed counter passes of this command
+    (over the passes' timed steps, where the summary tells those apart from the warm-up frames)."""
     path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_summary.json")
     try:
         for kernel, counters in json.load(open(path))[pas].items():
             if kernel.startswith(DOMINANT):
-                return counters[counter]["per_launch"]
+                return counters[counter].get("per_launch_timed_steps", counters[counter]["per_launch"])
     except Exception:
         pass
     return None

@@ -11,7 +11,7 @@ OUT=gpurun_out/prof_$TAG
 REPO=$(pwd)
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 20 --warmup 3"
+BENCH="python3 $REPO/bench.py --steps 20 --warmup 6"
 timeout -k 10 300 $BENCH > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/kt -o kt -- $BENCH --no-cpu-baseline --no-secondary > $REPO/$OUT/kt.log 2>&1

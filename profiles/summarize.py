@@ -2,7 +2,10 @@
 """Condenses the raw rocprofv3 output of profiles/collect.sh into the small files kept under profiles/.
 
   <tag>_bench.json            the bench.py line of the same run
-  <tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats: per-kernel calls / total / average ns
+  <tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats: per-kernel calls / total / average ns (all launches of
+                              the run: warm-up frames, with the first frame's growth and the second-tree try-out, included)
+  <tag>_kernel_timed.json     the dominant kernel's launches of the timed steps alone (the last `steps` of the trace):
+                              average / min / max duration, to set beside the bench line's roofline.avg_launch_ms
   <tag>_pmc_summary.json      per-kernel sums and per-launch averages of the counters of each --pmc pass
   traffic_trace_kernel.json   HBM-side bytes per launch of the dominant kernel (the persistent
                               traversal kernel): FETCH_SIZE doubled as the gfx950 note on that counter says
@@ -27,13 +30,23 @@ def short(name):
 
 def pmc_table(path):
     """{kernel: {counter: [sum, launches]}} from one counter_collection.csv (one row per dispatch x counter)."""
-    out = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    out = defaultdict(lambda: defaultdict(lambda: [0.0, 0, []]))
     with open(path) as f:
         for row in csv.DictReader(f):
             cell = out[short(row["Kernel_Name"])][row["Counter_Name"]]
             cell[0] += float(row["Counter_Value"])
             cell[1] += 1
+            cell[2].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
     return out
+
+
+def timed_mean(pairs, steps):
+    """Mean over the last `steps` dispatches (the bench's timed steps; the ones before are its warm-up frames)."""
+    per = defaultdict(float)
+    for d, v in pairs:
+        per[d] += v
+    vals = [per[d] for d in sorted(per)][-steps:]
+    return sum(vals) / max(1, len(vals))
 
 
 def main():
@@ -44,22 +57,41 @@ def main():
         shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
     for p in glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(p, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    steps = 20
+    if os.path.exists(os.path.join(src, "bench.json")):
+        try:
+            steps = int(json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])["steps"])
+        except (ValueError, KeyError, IndexError):
+            pass
+    for p in glob.glob(os.path.join(src, "kt", "**", "*kernel_trace.csv"), recursive=True):
+        durs = []
+        with open(p) as f:
+            for row in csv.DictReader(f):
+                if DOMINANT in row["Kernel_Name"]:
+                    durs.append((int(row["Dispatch_Id"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+        timed = [d for _, d in sorted(durs)][-steps:]
+        if timed:
+            json.dump({"kernel": DOMINANT, "launches_in_trace": len(durs), "timed_launches": len(timed),
+                       "avg_ns": sum(timed) / len(timed), "min_ns": min(timed), "max_ns": max(timed),
+                       "note": "the last `timed_launches` launches of the kernel in the --kernel-trace run: the bench's timed steps"},
+                      open(os.path.join(dst, f"{tag}_kernel_timed.json"), "w"), indent=1)
     summary = {}
     for pas in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_l2"):
         files = glob.glob(os.path.join(src, pas, "**", "*counter_collection.csv"), recursive=True)
         if not files:
             continue
         tab = pmc_table(files[0])
-        summary[pas] = {k: {c: {"sum": v[0], "launches": v[1], "per_launch": v[0] / max(1, v[1])} for c, v in cs.items()}
+        summary[pas] = {k: {c: {"sum": v[0], "launches": v[1], "per_launch": v[0] / max(1, v[1]),
+                                "per_launch_timed_steps": timed_mean(v[2], steps)} for c, v in cs.items()}
                         for k, cs in tab.items() if k.startswith("k_")}
     json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     fetch = write = None
     for k, cs in summary.get("pmc_fetch", {}).items():
         if DOMINANT in k and "FETCH_SIZE" in cs:
-            fetch = cs["FETCH_SIZE"]["per_launch"]
+            fetch = cs["FETCH_SIZE"]["per_launch_timed_steps"]
     for k, cs in summary.get("pmc_write", {}).items():
         if DOMINANT in k and "WRITE_SIZE" in cs:
-            write = cs["WRITE_SIZE"]["per_launch"]
+            write = cs["WRITE_SIZE"]["per_launch_timed_steps"]
     if fetch is not None:
         # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB
         fetch_b = fetch * 1024 * 2
