@@ -149,7 +149,9 @@ typedef struct rt_stats {
    /* device time, ms (HIP events on the stream the kernels run on) */
    float ms_total;              /* the whole frame, bracketed on the caller's stream */
    float ms_trace;              /* the persistent traversal launches (one per chunk of tiles) */
-   float ms_light, ms_combine, ms_resolve;
+   float ms_light, ms_combine, ms_resolve;   /* the kernels behind the traversal, timed one by one only for a scene made with
+                                              * RT_SCENE_COUNTERS (the events between them cost a few microseconds each);
+                                              * 0 otherwise: ms_total - ms_trace is what they took together */
    /* RT_SCENE_COUNTERS, single-chunk frames: when the waves of the traversal launch finished, measured from the
     * first wave's start (mean over waves, and the last one).  last >> mean = the launch is mostly its tail:
     * a few waves finishing long dependent bounce chains */

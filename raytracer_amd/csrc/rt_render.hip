@@ -421,6 +421,7 @@ struct TraceArgs {
    StackEntry *spill;           /* SPILL kernels: stack entries beyond the RT_LDS_STACK kept in LDS, [entry - RT_LDS_STACK][lane of the launch] */
    unsigned *dur;               /* when non-null: per queue entry, what the closest-hit ray cost: its own node steps + 4 x its leaf steps */
    unsigned *tile_bounce;       /* when non-null: per tile of the launch (zeroed), set when a primary of the tile spawns a bounce ray */
+   unsigned *tile_hit;          /* when non-null: per tile of the launch (zeroed), set when a primary of the tile hits something */
 };
 
 __device__ __forceinline__ QRay load_qray_rec(const QRay *q, unsigned long long i)
@@ -615,11 +616,19 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       } else {
          Hit h; h.prim = closest; h.t = t; a.hits[idx] = h;
          if (OUT == OUT_CHAIN) {
-            if (a.dur) a.dur[idx] = born;
             if (closest >= 0) {
+               if (a.dur) a.dur[idx] = born;
                pend = true;
-               if (tag == 1) store_qray(a.rays, idx, c.r.o, c.r.d, -FLT_MAX, 1);      /* a primary: made on fetch, not stored then (bounce rays are, when they are spawned) */
-            } else *reinterpret_cast<float4 *>(a.recs + idx) = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));   /* a miss: nothing to spawn */
+               if (tag == 1) {
+                  store_qray(a.rays, idx, c.r.o, c.r.d, -FLT_MAX, 1);      /* a primary: made on fetch, not stored then (bounce rays are, when they are spawned) */
+                  if (a.tile_hit) a.tile_hit[fd_div(idx, a.g.per_tile_div)] = 1u;
+               }
+            } else if (tag != 1) {
+               /* a bounce ray that hit nothing: nothing to spawn.  (Of a primary that hit nothing only the hit is stored:
+                * the kernels behind this one look at it first and want nothing else.) */
+               if (a.dur) a.dur[idx] = born;
+               *reinterpret_cast<float4 *>(a.recs + idx) = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));
+            }
          }
       }
    };
@@ -986,8 +995,6 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                      if (!inside) {
                         /* a slot outside the frame: the result of a miss, no follow-up work */
                         Hit h; h.prim = -1; h.t = FLT_MAX; a.hits[my] = h;
-                        *reinterpret_cast<float4 *>(a.recs + my) = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));
-                        if (a.dur) a.dur[my] = 0u;
                      }
                   } else q = load_qray_rec(a.rays, my);
 #ifdef RT_DEBUG_REFILL_CLK
@@ -1365,8 +1372,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_light(DScene sc, const QRay *queue
  * with vec3(0) for a ray that was not spawned or hit nothing.  One thread walks one tree (at most
  * 2^RT_MAX_RECURSE - 1 nodes, usually a short chain) with an explicit stack of one frame per level, so every
  * node is evaluated once, by one thread, in the reference's operand order: no atomics, no races. */
-__global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs, const float *totals, const unsigned *dur, long long n_primary, float *rgb,
-                                                           unsigned *tile_cost, unsigned per_tile, const unsigned *tile_bounce)
+__global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const Hit *hits, const SpawnRec *recs, const float *totals, const unsigned *dur, long long n_primary,
+                                                           float *rgb, unsigned *tile_cost, unsigned per_tile, const unsigned *tile_bounce)
 {
    /* one workgroup per tile: a tile without a bounce ray is left to k_resolve and costs one look at its flag */
    if (tile_bounce && tile_bounce[blockIdx.x] == 0u) return;
@@ -1374,12 +1381,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_combine_tree(const SpawnRec *recs,
       const bool live = i < n_primary;
       int node[RT_MAX_RECURSE], stage[RT_MAX_RECURSE];
       float rx[RT_MAX_RECURSE], ry[RT_MAX_RECURSE], rz[RT_MAX_RECURSE];
-      int sp = live ? 0 : -1;
+      /* a primary that hit nothing has no spawn record and no cost: its colour is the +0 the expression below gives for
+       * a light sum of 0 and weights 0, 0 */
+      const bool hit = live && hits[i].prim >= 0;
+      int sp = hit ? 0 : -1;
       unsigned chain_refl[RT_MAX_RECURSE];
       unsigned chain = 0;          /* the longest chain of dependent rays below (and with) the node just evaluated, in traversal steps of its rays */
       node[0] = (int)i; stage[0] = 0;
       F3 ret = mk3(0.0f, 0.0f, 0.0f);
-      if (live) {
+      if (hit) {
          /* most trees are a single node: the same expression with both children absent, without the stack */
          float4 rr = *reinterpret_cast<const float4 *>(recs + i);
          if (__float_as_int(rr.z) < 0 && __float_as_int(rr.w) < 0) {
@@ -1446,6 +1456,7 @@ struct ResolveShade {
    DScene sc;
    const QRay *queue; const Hit *hits; const SpawnRec *recs; const unsigned *flag_words; unsigned flag_stride; int shading;
    const unsigned *tile_bounce;     /* null: every tile went through k_light and k_combine_tree */
+   const unsigned *tile_hit;        /* with tile_bounce: clear for a tile none of whose primaries hit anything (nothing of it is read) */
    const unsigned *dur; unsigned *tile_cost;
 };
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DGrid g, const float *rgb, int n_batch_tiles, int out_layout,
@@ -1463,10 +1474,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DGrid g, const float *rgb,
    const bool here = rs.tile_bounce && rs.tile_bounce[k] == 0u;     /* uniform over the workgroup: 256 threads are a quarter of a tile */
    const bool inside = x < g.width && y < g.height;
    if (!inside && !here) return;
+   const bool empty = here && rs.tile_hit && rs.tile_hit[k] == 0u;       /* every sample of the tile is a miss: colour +0, cost 0 */
    F3 end = mk3(0.0f, 0.0f, 0.0f);
    long long tile_base = (long long)k * g.ts * g.ts;
    unsigned cost = 0, sum = 0;
-   for (int xo = 0; xo < g.sroot; xo++) {
+   for (int xo = 0; xo < g.sroot && !empty; xo++) {
       for (int yo = 0; yo < g.sroot; yo++) {
          int sx = lx * g.sroot + xo, sy = ly * g.sroot + yo;
          long long slot = tile_base + ((long long)((sy >> 3) * g.patches_per_row + (sx >> 3)) << 6) + ((sy & 7) << 3) + (sx & 7);
@@ -1480,8 +1492,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(DGrid g, const float *rgb,
                   const F3 none = mk3(0.0f, 0.0f, 0.0f);
                   F3 ret = total * (1.0f - rr.x - rr.y) + rr.x * none + rr.y * none;       /* kernel.cu:375-376 without children */
                   end = end + mk3(clamp01(ret.x), clamp01(ret.y), clamp01(ret.z));          /* kernel.cu:537-539 */
+                  if (rs.dur) { unsigned d = rs.dur[slot]; cost = d > cost ? d : cost; sum += d; }
                }
-               if (rs.dur) { unsigned d = rs.dur[slot]; cost = d > cost ? d : cost; sum += d; }
             }
          } else end = end + mk3(rgb[3 * slot], rgb[3 * slot + 1], rgb[3 * slot + 2]);
       }
@@ -1571,6 +1583,7 @@ struct rt_scene {
    unsigned long long *h_stats;  /* pinned */
    float node_factor;       /* queue entries per primary ray the chain kernel gets room for; grows when a frame overflows */
    StackEntry *d_spill;     /* trees deeper than RT_LDS_STACK: the stack entries beyond LDS, (depth - RT_LDS_STACK) x lanes of a full launch */
+   void *d_frame; size_t frame_cap;   /* rt_render's device copy of the frame, kept from call to call */
    uint2 *d_lists;          /* the waves' lists of spawned rays (k_trace): list_waves rings of list_cap entries */
    unsigned list_cap, list_waves;
    /* Tiles are started costliest first, by the previous frame's depth of the bounce trees per tile: the waves that
@@ -1579,6 +1592,7 @@ struct rt_scene {
    int *d_tile_order, *h_tile_order;      /* h_: pinned */
    long long order_cap;                   /* tiles the four arrays have room for */
    long long order_key[6];                /* width, height, samples, tile_first, tile_stride, tiles of the frame the order is for */
+   bool can_bounce;                       /* some material reflects or refracts: without one every ray tree is a single node */
    bool order_valid, order_dirty;         /* dirty: h_tile_order differs from what d_tile_order holds */
    /* The frame's work runs on one internal stream, chunk after chunk; the caller's stream only brackets it. */
    hipStream_t chain;
@@ -1640,6 +1654,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
    if (s->d_stats) (void)hipFree(s->d_stats);
    if (s->h_stats) (void)hipHostFree(s->h_stats);
    if (s->d_lists) (void)hipFree(s->d_lists);
+   if (s->d_frame) (void)hipFree(s->d_frame);
    if (s->d_spill) (void)hipFree(s->d_spill);
    if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
    if (s->d_tile_order) (void)hipFree(s->d_tile_order);
@@ -1670,7 +1685,7 @@ extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
    s->device = -1; s->flags = 0; s->streams_ok = false; s->ms_build_device = 0.0f;
    s->dev_blob = nullptr; s->dev_bytes = 0; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
    s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false; s->order_dirty = true;
-   s->d_lists = nullptr; s->list_cap = first_list_cap(); s->list_waves = 0; s->d_spill = nullptr;
+   s->d_lists = nullptr; s->list_cap = first_list_cap(); s->list_waves = 0; s->d_spill = nullptr; s->d_frame = nullptr; s->frame_cap = 0;
    s->camera = desc->camera; s->has_camera = desc->has_camera; s->ms_upload = 0;
    auto t0 = std::chrono::steady_clock::now();
    int st = rt_flatten_scene(desc, &s->host);
@@ -1695,7 +1710,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    s->device = device; s->flags = flags; s->streams_ok = false; s->ms_build_device = 0.0f;
    s->dev_blob = nullptr; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
    s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false; s->order_dirty = true;
-   s->d_lists = nullptr; s->list_cap = first_list_cap(); s->list_waves = 0; s->d_spill = nullptr;
+   s->d_lists = nullptr; s->list_cap = first_list_cap(); s->list_waves = 0; s->d_spill = nullptr; s->d_frame = nullptr; s->frame_cap = 0;
    s->camera = desc->camera; s->has_camera = desc->has_camera;
    scene_tuning(s);
    { char *unused = nullptr; (void)scratch_address(device, &unused); }   /* this device's static working memory (rt_trace_rays_static), looked up while the device is current; a failure is reported by that call */
@@ -1794,6 +1809,9 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
       if (s->filter_auto && h.n_prims > 0 && glass * 4 > (long long)h.n_prims) s->filter_choice = 0;
    }
    s->d.any_xform = h.any_xform;
+   /* a bounce ray needs a material with reflection or refraction above 0 (kernel.cu:360-374) */
+   s->can_bounce = false;
+   for (int k = 0; k < h.n_materials; k++) if (h.materials[k].refl > 0.0f || h.materials[k].refr > 0.0f) s->can_bounce = true;
 
    if (hipMalloc((void **)&s->d_ctr, RT_CTR_WORDS * sizeof(unsigned long long)) != hipSuccess ||
        hipMalloc((void **)&s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long)) != hipSuccess ||
@@ -1901,9 +1919,12 @@ struct EventPool {
       if (!spare.empty()) { *e = spare.back(); spare.pop_back(); return true; }
       return hipEventCreate(e) == hipSuccess;
    }
-   Timer &begin(hipStream_t st, float *acc)
+   /* `wanted` false: a timer that records nothing (an event between two kernels of a stream costs a few microseconds of
+    * the stream's time: only the runs that ask for the detail pay for it) */
+   Timer &begin(hipStream_t st, float *acc, bool wanted = true)
    {
       Timer t; t.acc = acc;
+      if (!wanted) { timers.push_back(t); return timers.back(); }
       t.ok = take(&t.a);
       if (t.ok && !take(&t.b)) { spare.push_back(t.a); t.ok = false; }
       if (t.ok) (void)hipEventRecord(t.a, st);
@@ -2036,6 +2057,10 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
                        float *t_dev, float *rgb_dev, hipStream_t stream, rt_stats *stats_out)
 {
    rt_scene *s = const_cast<rt_scene *>(cs);   /* the arena and counters are scratch state of the scene */
+#ifdef RT_DEBUG_HOST
+   static double dbg_acc[4]; static int dbg_n; static std::chrono::steady_clock::time_point dbg_prev_exit;
+   auto dbg_t0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::time_point dbg_t1, dbg_t2;
+#endif
    if (!s || !p) { rt_set_error("render: null argument"); return RT_ERR_BAD_ARGUMENT; }
    if (s->device < 0) { rt_set_error("scene was created without a device"); return RT_ERR_NO_DEVICE; }
    if (p->width <= 0 || p->height <= 0 || p->sample_count <= 0) { rt_set_error("render: non-positive size"); return RT_ERR_BAD_ARGUMENT; }
@@ -2124,7 +2149,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       const size_t o_flags = carve(flag_bytes);
       /* per tile of a chunk: did a primary of the tile spawn a bounce ray?  Tiles where none did are shaded in k_resolve */
       const bool fuse = view == VIEW_FRAME && s->fuse_resolve;
-      const size_t o_bounce = carve(sizeof(unsigned) * (size_t)chunk_tiles);
+      const size_t o_bounce = carve(sizeof(unsigned) * 2 * (size_t)chunk_tiles);      /* and, behind those, the same per tile for "hit anything" */
       const size_t slice = used;
       if (slice * (size_t)ring > s->arena.cap) { int rc = arena_reserve(s->arena, slice * (size_t)ring); if (rc != RT_OK) return rc; }
       { int rc = ensure_lists(s); if (rc != RT_OK) return rc; }
@@ -2170,10 +2195,10 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             /* counters to zero, spawned rays appended behind the primaries, tile costs and (first chunk) statistics cleared */
             const int n_stats = c == 0 ? ST_COUNT * RT_STAT_REPL : 0, n_cost = track_cost ? 2 * (int)n_sel : 0;
             int n_init = n_stats > n_cost ? (n_stats > RT_CTR_WORDS ? n_stats : RT_CTR_WORDS) : (n_cost > RT_CTR_WORDS ? n_cost : RT_CTR_WORDS);
-            if (fuse && (int)nb > n_init) n_init = (int)nb;
+            if (fuse && 2 * (int)nb > n_init) n_init = 2 * (int)nb;
             hipLaunchKernelGGL(k_begin_chunk, dim3(grid_for(n_init)), dim3(RT_BLOCK), 0, S, c == 0 ? s->d_stats : (unsigned long long *)nullptr,
                                n_stats, s->d_ctr, ctr.tail, (unsigned)np, track_cost ? s->d_tile_cost : (unsigned *)nullptr, n_cost,
-                               fuse ? AT(unsigned, r, o_bounce) : (unsigned *)nullptr, (int)nb);
+                               fuse ? AT(unsigned, r, o_bounce) : (unsigned *)nullptr, 2 * (int)nb);
             TraceArgs a; memset(&a, 0, sizeof a);
             a.rays = queue; a.n = (unsigned long long)np; a.hits = hits; a.next = ctr.next_chain;
             a.flag_words = AT(unsigned, r, o_flags); a.flag_stride = flag_stride;
@@ -2189,7 +2214,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
                a.tile_order = s->d_tile_order;
             }
             if (track_cost) a.dur = AT(unsigned, r, o_dur);
-            if (fuse) a.tile_bounce = AT(unsigned, r, o_bounce);
+            if (fuse) { a.tile_bounce = AT(unsigned, r, o_bounce); a.tile_hit = a.tile_bounce + nb; }
             Timer &tm = ev.begin(S, &st.ms_trace);
             launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, S, filter_kinds);
             ev.end(tm, S); st.launches_trace++;
@@ -2198,26 +2223,28 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             hipLaunchKernelGGL(k_unslot_hits, dim3(grid_for(np)), dim3(RT_BLOCK), 0, S, g, (const Hit *)hits, np, sc.prim_ids, sc.n_prims, prim_dev, t_dev);
             continue;
          }
-         {
-            Timer &tm = ev.begin(S, &st.ms_light);
+         /* A scene without a reflecting or refracting material spawns no bounce ray: every tile is k_resolve's then, and
+          * the two kernels before it have nothing to do. */
+         if (!(fuse && !s->can_bounce)) {
+            Timer &tm = ev.begin(S, &st.ms_light, count);
             hipLaunchKernelGGL(k_light, dim3((unsigned)nb + grid_for((long long)cap - np)), dim3(RT_BLOCK), 0, S, sc, (const QRay *)queue, (const Hit *)hits,
                                (const unsigned *)AT(unsigned, r, o_flags), flag_stride, (const unsigned *)ctr.tail, cap,
                                p->shading, AT(float, r, o_totals), fuse ? (const unsigned *)AT(unsigned, r, o_bounce) : (const unsigned *)nullptr,
                                (unsigned)np, (unsigned)per_tile);
             ev.end(tm, S);
-            Timer &tc = ev.begin(S, &st.ms_combine);
-            hipLaunchKernelGGL(k_combine_tree, dim3((unsigned)nb), dim3(RT_BLOCK), 0, S, (const SpawnRec *)recs,
+            Timer &tc = ev.begin(S, &st.ms_combine, count);
+            hipLaunchKernelGGL(k_combine_tree, dim3((unsigned)nb), dim3(RT_BLOCK), 0, S, (const Hit *)hits, (const SpawnRec *)recs,
                                (const float *)AT(float, r, o_totals), track_cost ? (const unsigned *)AT(unsigned, r, o_dur) : (const unsigned *)nullptr, np, AT(float, r, o_rgb),
                                track_cost ? s->d_tile_cost : (unsigned *)nullptr, (unsigned)per_tile,
                                fuse ? (const unsigned *)AT(unsigned, r, o_bounce) : (const unsigned *)nullptr);
             ev.end(tc, S);
          }
          if (view == VIEW_FRAME) {
-            Timer &tr = ev.begin(S, &st.ms_resolve);
+            Timer &tr = ev.begin(S, &st.ms_resolve, count);
             long long npx = nb * RT_TILE * RT_TILE;
             ResolveShade rs; memset(&rs, 0, sizeof rs);
             rs.sc = sc; rs.queue = queue; rs.hits = hits; rs.recs = recs; rs.flag_words = AT(unsigned, r, o_flags); rs.flag_stride = flag_stride;
-            rs.shading = p->shading; rs.tile_bounce = fuse ? AT(unsigned, r, o_bounce) : nullptr;
+            rs.shading = p->shading; rs.tile_bounce = fuse ? AT(unsigned, r, o_bounce) : nullptr; rs.tile_hit = fuse ? AT(unsigned, r, o_bounce) + nb : nullptr;
             rs.dur = track_cost ? AT(unsigned, r, o_dur) : nullptr; rs.tile_cost = track_cost ? s->d_tile_cost : nullptr;
             hipLaunchKernelGGL(k_resolve, dim3(grid_for(npx)), dim3(RT_BLOCK), 0, S, g, (const float *)AT(float, r, o_rgb), (int)nb,
                                p->out_layout, (uchar4 *)out_dev, rs);
@@ -2234,8 +2261,14 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       HIP_TRY(hipEventRecord(s->ev_end, M));
       HIP_TRY(hipStreamWaitEvent(stream, s->ev_end, 0));
       ev.end(t_total, stream);
+#ifdef RT_DEBUG_HOST
+      dbg_t1 = std::chrono::steady_clock::now();
+#endif
       HIP_TRY(hipStreamSynchronize(stream));
       HIP_TRY(hipStreamSynchronize(M));
+#ifdef RT_DEBUG_HOST
+      dbg_t2 = std::chrono::steady_clock::now();
+#endif
       HIP_TRY(hipGetLastError());
       ev.collect();
       if (sum_stat(s->h_stats, ST_ABORTED) != 0) { rt_set_error("traversal aborted: step cap reached (corrupt scene?)"); return RT_ERR_HIP; }
@@ -2356,6 +2389,16 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       st.wave_exit_last_ms = (float)(((double)s->h_stats[ST_CLOCK_LAST_EXIT * RT_STAT_REPL] - first) * 1e-5);
    }
    if (stats_out) *stats_out = st;
+#ifdef RT_DEBUG_HOST
+   {
+      auto t3 = std::chrono::steady_clock::now();
+      auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+      if (dbg_n > 0) dbg_acc[3] += us(dbg_prev_exit, dbg_t0);
+      dbg_acc[0] += us(dbg_t0, dbg_t1); dbg_acc[1] += us(dbg_t1, dbg_t2); dbg_acc[2] += us(dbg_t2, t3); dbg_n++;
+      dbg_prev_exit = t3;
+      if (dbg_n % 10 == 0) { fprintf(stderr, "host us per frame: enqueue %.1f, wait %.1f, after %.1f, outside the call %.1f\n", dbg_acc[0] / 10, dbg_acc[1] / 10, dbg_acc[2] / 10, dbg_acc[3] / 10); dbg_acc[0] = dbg_acc[1] = dbg_acc[2] = dbg_acc[3] = 0; }
+   }
+#endif
    return RT_OK;
 }
 
@@ -2375,15 +2418,21 @@ extern "C" int rt_render(const rt_scene *scene, const rt_render_params *params, 
    rt_render_params p = *params;
    p.out_layout = RT_OUT_FRAME;
    size_t bytes = (size_t)p.width * (size_t)p.height * 4;
-   void *d_out = nullptr;
-   HIP_TRY(hipMalloc(&d_out, bytes));
-   hipError_t e = hipMemset(d_out, 0, bytes);
+   rt_scene *s = const_cast<rt_scene *>(scene);      /* the frame buffer is scratch state of the scene */
+   if (bytes > s->frame_cap) {
+      if (s->d_frame) { (void)hipFree(s->d_frame); s->d_frame = nullptr; s->frame_cap = 0; }
+      HIP_TRY(hipMalloc(&s->d_frame, bytes));
+      s->frame_cap = bytes;
+   }
+   void *d_out = s->d_frame;
+   /* pixels of tiles this call does not select read as 0 */
+   const bool all_tiles = p.tile_first == 0 && p.tile_stride <= 1;
+   hipError_t e = all_tiles ? hipSuccess : hipMemset(d_out, 0, bytes);
    int rc = e == hipSuccess ? render_impl(scene, &p, VIEW_FRAME, d_out, nullptr, nullptr, nullptr, nullptr, stats) : RT_ERR_HIP;
    if (rc == RT_OK) {
       e = hipMemcpy(out_host, d_out, bytes, hipMemcpyDeviceToHost);   /* kernel.cu:759-760 */
       if (e != hipSuccess) { rt_set_error("frame copy failed: %s", hipGetErrorString(e)); rc = RT_ERR_HIP; }
    }
-   (void)hipFree(d_out);
    return rc;
 }
 

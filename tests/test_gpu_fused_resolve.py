@@ -99,3 +99,54 @@ def test_frame_is_the_average_of_the_samples():
     px = (acc / np.float32(spp) * np.float32(255.0))
     want = np.clip(np.nan_to_num(px, nan=0.0).astype(np.int64), 0, 255).astype(np.uint8)
     assert np.array_equal(frame[:, :, :3], want)
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("name", ["balls2", "bunny"])
+def test_nothing_is_read_from_the_frame_before(name, fuse):
+    """A primary that hits nothing stores only its hit; its spawn record and cost keep whatever an earlier frame (another
+    camera, another frame size) left in the queue memory, and nothing may read them."""
+    sd = ra.SceneData.load(os.path.join(G, name + ".npz"))
+    cam = sd.camera
+    cam2 = {"pos": cam["pos"] * np.float32(1.6) + np.array([0.4, 0.2, -0.3], np.float32), "up": cam["up"], "right": cam["right"],
+            "look_at": cam["look_at"]}
+    sd2 = ra.SceneData.load(os.path.join(G, name + ".npz"))
+    sd2.camera = cam2
+    with scene_with(fuse, sd2) as sc:
+        want, _ = sc.render(300, 200, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, 5)
+    with scene_with(fuse, sd) as sc:
+        sc.render(300, 200, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, 5)
+        sc.render(420, 330, 4, abi.RT_PHONG, abi.RT_JITTER_HASH, 5)         # other slots, other hits
+        sc.set_camera(cam2["pos"], cam2["up"], cam2["right"], cam2["look_at"])
+        got, _ = sc.render(300, 200, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, 5)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_tile_subset_after_a_whole_frame():
+    """rt_render keeps its device copy of the frame from call to call: pixels of tiles a later call does not select are 0."""
+    sd = ra.SceneData.load(os.path.join(G, "cornell.npz"))
+    w, h = 160, 128
+    with ra.Scene(sd) as sc:
+        whole, _ = sc.render(w, h, 1, abi.RT_PHONG, abi.RT_JITTER_NONE)
+        part, _ = sc.render(w, h, 1, abi.RT_PHONG, abi.RT_JITTER_NONE, tile_first=1, tile_stride=2)
+        again, _ = sc.render(w, h, 1, abi.RT_PHONG, abi.RT_JITTER_NONE)
+    tiles_x = (w + abi.RT_TILE - 1) // abi.RT_TILE
+    for ty in range((h + abi.RT_TILE - 1) // abi.RT_TILE):
+        for tx in range(tiles_x):
+            block = part[ty * abi.RT_TILE:(ty + 1) * abi.RT_TILE, tx * abi.RT_TILE:(tx + 1) * abi.RT_TILE]
+            ref = whole[ty * abi.RT_TILE:(ty + 1) * abi.RT_TILE, tx * abi.RT_TILE:(tx + 1) * abi.RT_TILE]
+            if (ty * tiles_x + tx) % 2 == 1:
+                assert np.array_equal(block, ref)
+            else:
+                assert not block.any()
+    assert again.tobytes() == whole.tobytes()
+
+
+def test_per_kernel_times_only_with_counters():
+    sd = ra.SceneData.load(os.path.join(G, "balls2.npz"))
+    with ra.Scene(sd) as sc:
+        _, st = sc.render(200, 150, 1, abi.RT_PHONG, abi.RT_JITTER_HASH)
+    assert st["ms_trace"] > 0 and st["ms_total"] > st["ms_trace"] and st["ms_light"] == 0 and st["ms_resolve"] == 0
+    with ra.Scene(sd, counters=True) as sc:
+        _, st = sc.render(200, 150, 1, abi.RT_PHONG, abi.RT_JITTER_HASH)
+    assert st["ms_light"] > 0 and st["ms_combine"] > 0 and st["ms_resolve"] > 0

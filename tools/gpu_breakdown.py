@@ -36,8 +36,8 @@ def run(name):
     st = best
     nv = ct["node_visits"] + ct["node_visits_shadow"]
     npt = ct["prim_tests"] + ct["prim_tests_shadow"]
-    print(f"{name}: {w}x{h} spp{spp}: total {st['ms_total']:.3f} ms = trace {st['ms_trace']:.3f} + light {st['ms_light']:.3f} + combine "
-          f"{st['ms_combine']:.3f} + resolve {st['ms_resolve']:.3f}; rays {st['rays_total'] / 1e6:.2f} M (primary {st['rays_primary'] / 1e6:.2f}, "
+    print(f"{name}: {w}x{h} spp{spp}: total {st['ms_total']:.3f} ms = trace {st['ms_trace']:.3f} + the rest {st['ms_total'] - st['ms_trace']:.3f} (counted run: light {ct['ms_light']:.3f}, combine "
+          f"{ct['ms_combine']:.3f}, resolve {ct['ms_resolve']:.3f}); rays {st['rays_total'] / 1e6:.2f} M (primary {st['rays_primary'] / 1e6:.2f}, "
           f"shadow {st['rays_shadow'] / 1e6:.2f}, bounce {(st['rays_reflect'] + st['rays_refract']) / 1e6:.2f}) -> "
           f"{st['rays_total'] / st['ms_total'] / 1e3:.0f} Mrays/s", flush=True)
     print(f"   counted: trace {ct['ms_trace']:.3f} ms, node visits/ray {nv / ct['rays_total']:.1f}, prim tests/ray {npt / ct['rays_total']:.2f}, "
