@@ -182,6 +182,9 @@ typedef struct rt_stats {
     * tie window and whose leaf the reference's walk provably reaches (answered without that walk); rays with a rival
     * (the reference's walk was made); rays for which the reach of the leaf could not be shown (likewise) */
    uint64_t hits_certified, hits_contested, hits_unreached;
+   /* likewise: feelers reported "shadowed" from a primitive met in the second tree, clear of the target by more than
+    * EQUAL_EPSILON, whose leaf the reference's walk provably reaches (the other shadowed feelers made that walk) */
+   uint64_t shadows_certified;
 } rt_stats;
 
 typedef struct rt_scene_info {

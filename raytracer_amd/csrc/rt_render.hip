@@ -119,7 +119,7 @@ struct SpawnRec {
 
 enum { ST_SHADOW_SKIPPED = 0, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES,
        ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
-       ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_CERT_OK, ST_CERT_RIVAL, ST_CERT_UNREACHED, ST_LEAF_WAIT, ST_NO_RAY, ST_REFILLS, ST_CLK_REFILL, ST_CLK_NODE, ST_CLK_LEAF, ST_CLK_WAVE,
+       ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_CERT_OK, ST_CERT_RIVAL, ST_CERT_UNREACHED, ST_SHADOW_CERT, ST_LEAF_WAIT, ST_NO_RAY, ST_REFILLS, ST_CLK_REFILL, ST_CLK_NODE, ST_CLK_LEAF, ST_CLK_WAVE,
        ST_ABORTED, ST_MAX_RAY_STEPS, ST_MAX_LIST, ST_OVERFLOW, ST_LIST_OVERFLOW,
        ST_CLOCK_FIRST_START, ST_CLOCK_LAST_EXIT, ST_CLOCK_EXIT_SUM, ST_WAVES,
 #ifdef RT_DEBUG_EXIT_HIST
@@ -369,7 +369,9 @@ __device__ __forceinline__ Ray camera_ray(const DCamera &cam, const DGrid &g, in
 enum { OUT_HIT = 0, OUT_CHAIN = 2 };
 enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2, MODE_KIND = 3,
        MODE_FILTER = 4,     /* set while the ray is still in the second tree (see enter_tree below) */
-       MODE_VERIFY = 8 };   /* set while the ray walks the reference's tree from the root down to one leaf */
+       MODE_VERIFY = 8,     /* set while the ray walks the reference's tree from the root down to one leaf */
+       /* a feeler in the second tree, about the primitives it has met in front of its target (see the leaf step) */
+       MODE_BAND = 16 };    /* one within EPSILON of the target: the reference's walk would stop at it and report "lit" */
 /* How far beyond the nearest hit so far a closest-hit ray still looks in the second tree: every box that starts
  * within RT_LOOK_ABS + t * RT_LOOK_REL behind it.  It has to know of every primitive within EQUAL_EPSILON of its
  * nearest one; the rest of the margin is allowance for a primitive's computed parameter lying in front of where its
@@ -387,14 +389,18 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2, MODE_KIND = 3,
 #define RT_LEAF_TRIGGER 24  /* lanes waiting at a leaf that end a burst of node steps early */
 #define RT_FETCH_STREAMS 64u /* counters the primaries are handed out through */
 #define RT_CTR_WORDS (8 * ((int)RT_FETCH_STREAMS + 1))   /* 64-bit words of a launch's counters: the streams' (64 bytes apart), then the queue tail */
+#define RT_LONG_FEELER 128u  /* a feeler of a primary that cost more than this raises its tile's cost (k_trace) */
 #define RT_ORDER_CLASSES 256 /* classes of tile cost that decide the order in which a frame's tiles are started */
 #define RT_ORDER_MEAN_WEIGHT 4
 #define RT_LDS_STACK 16     /* stack entries per lane kept in LDS; deeper trees spill the rest to global memory */
 #define RT_RESERVE 256      /* queue entries a wave reserves at a time for the bounce rays it spawns */
 
 #ifdef RT_DEBUG_WAVES
-__device__ unsigned long long dbg_waves[4096 * 8];
-extern "C" int rt_debug_read_waves(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dbg_waves), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : 1; }
+#define RT_DBG_RAY_START dbg_ray_start = wall_clock64()
+__device__ unsigned long long dbg_waves[4096 * 16];
+extern "C" int rt_debug_read_waves(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dbg_waves), sizeof(unsigned long long) * 4096 * 16) == hipSuccess ? 0 : 1; }
+#else
+#define RT_DBG_RAY_START (void)0
 #endif
 struct TraceArgs {
    QRay *rays;                  /* the queue; OUT_CHAIN appends spawned rays behind the first n */
@@ -422,6 +428,7 @@ struct TraceArgs {
    unsigned *dur;               /* when non-null: per queue entry, what the closest-hit ray cost: its own node steps + 4 x its leaf steps */
    unsigned *tile_bounce;       /* when non-null: per tile of the launch (zeroed), set when a primary of the tile spawns a bounce ray */
    unsigned *tile_hit;          /* when non-null: per tile of the launch (zeroed), set when a primary of the tile hits something */
+   unsigned *tile_cost;         /* when non-null: two words per tile of the launch (zeroed); the first is raised to the cost of a long feeler of one of the tile's primaries */
 };
 
 __device__ __forceinline__ QRay load_qray_rec(const QRay *q, unsigned long long i)
@@ -551,6 +558,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
 #ifdef RT_DEBUG_WAVES
    const unsigned long long dbg_t0 = wall_clock64();
    unsigned long long dbg_last_fetch = 0, dbg_last_spawn = 0, dbg_list_at_dry = ~0ULL; unsigned dbg_fetched = 0, dbg_refills = 0;
+   /* per lane: when its current ray started; of the last ray it finished: when, when that one started, and mode | tag << 8 | born << 16 */
+   unsigned long long dbg_ray_start = 0, dbg_fin_clock = 0, dbg_fin_start = 0, dbg_fin_info = 0;
 #endif
 
    unsigned long long guard = 0;       /* wave-uniform: turns of the loop below */
@@ -584,6 +593,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
 #ifdef RT_DEBUG_REFILL_CLK
    unsigned long long dbg_wait = 0, dbg_pre = 0, dbg_c = 0, dbg_d = 0;
 #endif
+   unsigned n_shadow_cert = 0;                          /* COUNT only: feelers reported "shadowed" from the second tree and one path of the reference's */
    unsigned n_cert = 0, n_rival = 0, n_unreached = 0;   /* COUNT only: how this lane's closest-hit rays left the second tree with a hit */
    unsigned n_leafwait = 0, n_noray = 0, n_refills = 0;   /* COUNT only: node steps this lane sat out at a leaf / without a ray; refills of the wave */
 
@@ -601,18 +611,39 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          else { mode = MODE_EXTEND; toBeat = -FLT_MAX; t = FLT_MAX; closest = -1; cur = sc.root; sp = 0; }
          return;
       }
+      if (OUT == OUT_CHAIN && (mode & (MODE_KIND | MODE_FILTER)) == (MODE_SHADOW | MODE_FILTER) && closest >= 0) {
+         /* A feeler that has searched the second tree and met something in front of its target.  The reference's walk
+          * stops at the first primitive it accepts with a parameter below the target's (kernel.cu:117-121, 128-132) and
+          * reports "shadowed" if that parameter is below it by more than EPSILON (kernel.cu:206).  `closest` is in front
+          * by more than EQUAL_EPSILON, so no tie with a hit at or beyond the target can keep the walk from accepting it;
+          * nothing the ray meets lies in the last EPSILON before the target (MODE_BAND is clear), so whatever the walk
+          * accepts first, it reports "shadowed" -- provided it reaches the leaf of `closest` if it accepts nothing else
+          * before, and that is checked on the reference's tree, along the one path from its root to that leaf.
+          * (With anything less clear-cut the feeler has left the second tree at once: see the leaf step.) */
+         if (COUNT) n_shadow_cert++;
+         mode = MODE_SHADOW | MODE_VERIFY; t = __int_as_float(sc.leaf_parent[closest]); cur = sc.root;
+         return;
+      }
       if (COUNT) { max_ray_steps = ray_steps > max_ray_steps ? ray_steps : max_ray_steps; }
       if (!early) plane_scan(sc, c.r, t, closest);
-      if (OUT == OUT_CHAIN && mode == (MODE_SHADOW | MODE_FILTER) && t < toBeat) {
+      if (OUT == OUT_CHAIN && (mode & (MODE_KIND | MODE_FILTER | MODE_VERIFY)) == (MODE_SHADOW | MODE_FILTER) && t < toBeat) {
          /* A feeler the filter found nothing for, but with a plane in front of its target: whether that plane counts
           * depends, within EPSILON, on what the reference's walk leaves in t, so that walk is made after all. */
          mode = MODE_SHADOW; cur = sc.root; sp = 0; t = FLT_MAX; closest = -1;
          return;
       }
       active = false; cur = RT_CUR_IDLE;
+#ifdef RT_DEBUG_WAVES
+      dbg_fin_clock = wall_clock64(); dbg_fin_start = dbg_ray_start;
+      dbg_fin_info = (unsigned long long)(unsigned)mode | ((unsigned long long)(unsigned)(tag & 0xff) << 8) | ((unsigned long long)born << 16);
+#endif
       if (OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND) {
          /* kernel.cu:206; a feeler that is not shadowed leaves its bit as the launch found it: clear */
          if (less_than(t, toBeat)) atomicOr(a.flag_words + (size_t)idx * a.flag_stride + ((unsigned)tag >> 5), 1u << ((unsigned)tag & 31u));
+         /* A feeler that took long (the reference's walk, for one the second tree could not answer) belongs to a tile
+          * that should start early next frame: the tile's cost is at least this feeler's.  (Only the feelers of
+          * primaries say which tile they belong to; they are few.) */
+         if (a.tile_cost && born > RT_LONG_FEELER && idx < (unsigned)a.n) atomicMax(a.tile_cost + 2 * fd_div(idx, a.g.per_tile_div), born);
       } else {
          Hit h; h.prim = closest; h.t = t; a.hits[idx] = h;
          if (OUT == OUT_CHAIN) {
@@ -713,10 +744,18 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
           * t the walk can hold before it reaches that leaf, and the least of those is beyond t + EQUAL_EPSILON
           * (kernel.cu:139-175).  If not, nothing is known: the reference's walk is made in full. */
          if (mode & MODE_VERIFY) {
-            const int hangs_at = __float_as_int(toBeat);
+            /* (a feeler on that way keeps the node number in t and its target's parameter in toBeat: the reference's walk
+             * holds no t below the target's parameter before it stops) */
+            const bool feeler = (mode & MODE_KIND) != MODE_EXTEND;
+            const int hangs_at = __float_as_int(feeler ? t : toBeat);
+            const float limit = feeler ? toBeat : t + RT_EQ_EPS;
             const bool right_turn = ch.y >= 0 ? hangs_at >= ch.y : ~ch.y == closest;
-            if ((right_turn ? r : l) < t + RT_EQ_EPS) cur = right_turn ? ch.y : ch.x;      /* at the leaf: the leaf step ends the ray */
-            else { mode = MODE_EXTEND; toBeat = -FLT_MAX; t = FLT_MAX; closest = -1; cur = sc.root; sp = 0; if (COUNT) { n_cert--; n_unreached++; } }
+            if ((right_turn ? r : l) < limit) cur = right_turn ? ch.y : ch.x;      /* at the leaf: the leaf step ends the ray */
+            else {
+               if (COUNT) { if (feeler) { n_shadow_cert--; } else { n_cert--; n_unreached++; } }
+               mode &= MODE_KIND; t = FLT_MAX; closest = -1; cur = sc.root; sp = 0;
+               if (!feeler) toBeat = -FLT_MAX;
+            }
             return;
          }
       }
@@ -851,7 +890,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          if (!sc.fast_ok) c.fast = false;
          toBeat = -FLT_MAX; idx = (unsigned)(cont_refl ? out.child_refl : out.child_refr); tag = tag + 1; mode = MODE_EXTEND;
          t = FLT_MAX; closest = -1; sp = 0; enter_tree();
-         active = true; ray_steps = 0; born = 0;
+         active = true; ray_steps = 0; born = 0; RT_DBG_RAY_START;
          if (cur == RT_ROOT_EMPTY) finish(false);
       }
       return front_pushed;
@@ -950,7 +989,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                c = make_ctx(feeler);
                if (!sc.fast_ok) c.fast = false;
                tag = (int)k; idx = node;
-               t = FLT_MAX; closest = -1; sp = 0; ray_steps = 0; born = 0;
+               t = FLT_MAX; closest = -1; sp = 0; ray_steps = 0; born = 0; RT_DBG_RAY_START;
                if (hprim >= sc.n_prims) {
                   /* planes are not in the tree: their own-surface test is done here */
                   float param = plane_intersect(sc, hprim - sc.n_prims, feeler);   /* kernel.cu:351 */
@@ -1006,7 +1045,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                      if (!sc.fast_ok) c.fast = false;
                      toBeat = q.to_beat; idx = (unsigned)my; tag = q.valid; mode = MODE_EXTEND;
                      t = FLT_MAX; closest = -1; sp = 0; enter_tree();
-                     active = true; ray_steps = 0; born = 0;
+                     active = true; ray_steps = 0; born = 0; RT_DBG_RAY_START;
                      if (cur == RT_ROOT_EMPTY) finish(false);
                   }
                }
@@ -1068,11 +1107,18 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             float dist = 0.0f;
             if (!(OUT == OUT_CHAIN && (mode & MODE_VERIFY))) dist = prim_intersect(sc, ~cur, c.r);
             if (OUT == OUT_CHAIN && (mode & MODE_VERIFY)) {
-               /* the way down from the root has arrived: the reference's walk tests this leaf too, so its answer is
-                * `closest` at t; on to the planes (the stack is empty, the pop below ends the ray) */
-               mode = MODE_EXTEND; toBeat = -FLT_MAX; sp = 0;
-               if (~cur == closest) tested = true;
-               else { t = FLT_MAX; closest = -1; cur = sc.root; if (COUNT) { n_cert--; n_unreached++; } }       /* not the leaf it set out for: the reference's walk in full */
+               /* the way down from the root has arrived: the reference's walk tests this leaf too.  A closest-hit ray's
+                * answer is `closest` at t; on to the planes (the stack is empty, the pop below ends the ray).  A feeler's
+                * walk stops here at the latest, with a parameter that reports "shadowed". */
+               const bool feeler = (mode & MODE_KIND) != MODE_EXTEND;
+               mode &= MODE_KIND; sp = 0;
+               if (!feeler) toBeat = -FLT_MAX;
+               if (~cur == closest) { tested = true; if (feeler) { take = true; leaf_dist = -FLT_MAX; } }
+               else {
+                  /* not the leaf it set out for: the reference's walk in full */
+                  t = FLT_MAX; closest = -1; cur = sc.root;
+                  if (COUNT) { if (feeler) { n_shadow_cert--; } else { n_cert--; n_unreached++; } }
+               }
             } else if (mode & MODE_FILTER) {
                /* still in the filter's tree: does the ray meet this primitive where it could matter? */
                bool shadow = OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND;
@@ -1085,10 +1131,26 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                      else toBeat = fminf(toBeat, dist);
                   }
                   tested = true;
+               } else if (shadow) {
+                  /* A feeler: a primitive the reference's walk would accept and stop at (in front of the target, not
+                   * behind the origin) is sorted by how far in front it is -- within EPSILON the walk reports "lit",
+                   * within EQUAL_EPSILON a tie with a hit at the target's distance may make it pass the primitive by,
+                   * further in front it takes it and reports "shadowed".  The first of the last kind is kept, and the
+                   * search goes on for one of the first kind (take stays false: on to the next deferred box); finish()
+                   * sees to the rest when the tree has been searched.  With one that says "lit" and one that says
+                   * "shadowed", or one that depends on a tie and none that is clear of it yet, the order of the
+                   * reference's walk decides: that walk is made, from its root. */
+                  bool order_decides = false;
+                  if (above_zero(dist) && dist < toBeat) {
+                     if (!less_than(dist, toBeat)) { mode |= MODE_BAND; order_decides = closest >= 0; }
+                     else if (dist + RT_EQ_EPS > toBeat) order_decides = closest < 0;
+                     else { if (closest < 0) closest = ~cur; order_decides = (mode & MODE_BAND) != 0; }
+                  }
+                  if (order_decides) leave_filter();
+                  else tested = true;
                } else {
-                  const bool matters = above_zero(dist) && (!shadow || less_than(dist, toBeat));
-                  if (matters) leave_filter();     /* the reference's walk, from its root */
-                  else tested = true;              /* take stays false: on to the next deferred box */
+                  if (above_zero(dist)) leave_filter();     /* the reference's walk, from its root */
+                  else tested = true;                       /* take stays false: on to the next deferred box */
                }
             } else if (OUT == OUT_CHAIN && mode == MODE_SETUP) {
                /* the feeler against its own surface (kernel.cu:351).  A feeler that misses it (-1) can never be
@@ -1132,9 +1194,19 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    }
 #ifdef RT_DEBUG_WAVES
    if (lane == 0) {
-      unsigned long long *w = dbg_waves + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+      unsigned long long *w = dbg_waves + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
       w[0] = dbg_t0; w[1] = dbg_last_fetch; w[2] = wall_clock64(); w[3] = (unsigned long long)list_peak; w[4] = dbg_fetched; w[5] = dbg_refills;
       w[6] = dbg_last_spawn; w[7] = dbg_list_at_dry;
+   }
+   {
+      /* the ray the wave finished last */
+      unsigned long long latest = dbg_fin_clock;
+      for (int o = 32; o > 0; o >>= 1) { unsigned long long other = __shfl_xor(latest, o); latest = other > latest ? other : latest; }
+      const unsigned long long mine = __ballot(dbg_fin_clock == latest);
+      if (mine && lane == (unsigned)__builtin_ctzll(mine)) {
+         unsigned long long *w = dbg_waves + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+         w[8] = dbg_fin_clock; w[9] = dbg_fin_start; w[10] = dbg_fin_info;
+      }
    }
 #endif
 #ifdef RT_DEBUG_EXIT_HIST
@@ -1171,6 +1243,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
 #endif
       stat_add(stats, ST_CERT_OK, (unsigned long long)n_cert); stat_add(stats, ST_CERT_RIVAL, (unsigned long long)n_rival);
       stat_add(stats, ST_CERT_UNREACHED, (unsigned long long)n_unreached);
+      stat_add(stats, ST_SHADOW_CERT, (unsigned long long)n_shadow_cert);
       stat_add(stats, ST_LEAF_WAIT, (unsigned long long)n_leafwait);
       stat_add(stats, ST_NO_RAY, (unsigned long long)n_noray);
       if (lane == 0) {
@@ -2213,7 +2286,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
                }
                a.tile_order = s->d_tile_order;
             }
-            if (track_cost) a.dur = AT(unsigned, r, o_dur);
+            if (track_cost) { a.dur = AT(unsigned, r, o_dur); a.tile_cost = s->d_tile_cost; }
             if (fuse) { a.tile_bounce = AT(unsigned, r, o_bounce); a.tile_hit = a.tile_bounce + nb; }
             Timer &tm = ev.begin(S, &st.ms_trace);
             launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, S, filter_kinds);
@@ -2358,6 +2431,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    st.wave_refills = sum_stat(s->h_stats, ST_REFILLS);
    st.hits_certified = sum_stat(s->h_stats, ST_CERT_OK); st.hits_contested = sum_stat(s->h_stats, ST_CERT_RIVAL);
    st.hits_unreached = sum_stat(s->h_stats, ST_CERT_UNREACHED);
+   st.shadows_certified = sum_stat(s->h_stats, ST_SHADOW_CERT);
    {
       double w = (double)sum_stat(s->h_stats, ST_CLK_WAVE);
       st.wave_time_refill = w > 0 ? (float)((double)sum_stat(s->h_stats, ST_CLK_REFILL) / w) : 0.0f;

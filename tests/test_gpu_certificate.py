@@ -47,7 +47,7 @@ def both_ways(sd, w, h, spp=1, shading=abi.RT_PHONG, seed=7, oracle=True):
     assert f1.tobytes() == f0.tobytes()
     for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "shade_nodes", "shadow_skipped"):
         assert s1[k] == s0[k], k
-    assert s0["hits_certified"] == 0 and s0["hits_contested"] == 0 and s0["hits_unreached"] == 0
+    assert s0["hits_certified"] == 0 and s0["hits_contested"] == 0 and s0["hits_unreached"] == 0 and s0["shadows_certified"] == 0
     if oracle:
         osc = orclib.OracleScene(sd)
         try:
@@ -136,3 +136,33 @@ def test_full_frame_balls2_counts():
     sd = ra.SceneData.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes", "balls2.npz"))
     st = both_ways(sd, 480, 270, 1, oracle=False)
     assert st["hits_certified"] > 5 * (st["hits_contested"] + st["hits_unreached"]) // 4
+
+
+# ---- feelers: "shadowed" from the second tree -------------------------------------------------------------------------
+# A feeler's parameter runs from 0 at the light to about 1 at its target, so EPSILON (1e-4) and EQUAL_EPSILON (1e-2) are
+# fractions of the light's distance.  With the lights of layered() about 10 away, a copy of the layer 0.0005 in front of
+# a point lies in the last EPSILON before it (the reference's walk stops there and says "lit"), one 0.05 in front within
+# EQUAL_EPSILON (a tie with the point's own triangle may make the walk pass it by), one 0.3 or 1.0 in front is clear of
+# both: only those may be answered without the reference's walk.  (The triangles of a layer also shadow each other, from
+# further away.)
+@pytest.mark.parametrize("offsets", [(0.0005,), (0.0005, 0.3), (0.05,), (0.05, 0.3), (0.3, 1.0), (0.0009, 0.0011, 0.09, 0.11)])
+def test_feelers_and_layers_around_their_target(offsets):
+    st = both_ways(layered(offsets), 240, 160, 1)
+    assert st["shadows_certified"] > 0
+
+
+def test_feelers_from_a_distant_light_are_never_certified():
+    """From 1000 away everything near the target is within EQUAL_EPSILON of it."""
+    sd = layered((0.3, 1.0))
+    sd.lights["pos"] = [(300.0, 500.0, 900.0), (-400.0, 200.0, 600.0)]
+    st = both_ways(sd, 240, 160, 1)
+    assert st["shadows_certified"] == 0 and st["rays_shadow"] > 0
+
+
+def test_feelers_certified_in_crowded_scenes_and_on_the_flake():
+    sd = synth.random_scene(321, n_spheres=150, n_triangles=150, n_boxes=40, n_smooth=60, n_planes=1, n_lights=3)
+    st = both_ways(sd, 200, 150, 4)
+    assert st["shadows_certified"] > 0
+    sd = ra.SceneData.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes", "balls2.npz"))
+    st = both_ways(sd, 320, 180, 1, oracle=False)
+    assert st["shadows_certified"] > st["rays_shadow"] // 10
