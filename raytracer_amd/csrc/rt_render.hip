@@ -389,6 +389,9 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2, MODE_KIND = 3,
 #define RT_LEAF_TRIGGER 24  /* lanes waiting at a leaf that end a burst of node steps early */
 #define RT_FETCH_STREAMS 64u /* counters the primaries are handed out through */
 #define RT_CTR_WORDS (8 * ((int)RT_FETCH_STREAMS + 1))   /* 64-bit words of a launch's counters: the streams' (64 bytes apart), then the queue tail */
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 4  /* resident waves per SIMD the traversal kernel is compiled for (128 registers per lane) */
+#endif
 #define RT_LONG_FEELER 128u  /* a feeler of a primary that cost more than this raises its tile's cost (k_trace) */
 #define RT_ORDER_CLASSES 256 /* classes of tile cost that decide the order in which a frame's tiles are started */
 #define RT_ORDER_MEAN_WEIGHT 4
@@ -513,8 +516,10 @@ __device__ __forceinline__ BounceRays bounce_rays(const rt_dev_prim *prims, cons
    return b;
 }
 
-template <int OUT, bool COUNT, bool SPILL>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_trace(DScene sc, TraceArgs a)
+/* TWO: the launch uses the scene's second tree (sc.filter_root is one); without it none of the code that proves answers
+ * from that tree is there */
+template <int OUT, bool COUNT, bool SPILL, bool TWO>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_SIMD, RT_WAVES_PER_SIMD))) void k_trace(DScene sc, TraceArgs a)
 {
    /* The per-lane stack of deferred siblings: one column per lane in LDS.  A tree deeper than RT_LDS_STACK levels
     * (SPILL) keeps the entries beyond that in global memory, a column per lane of the launch, so that deep trees do
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
 
    /* a ray is finished: scan the planes unless it left early, write its result */
    auto finish = [&](bool early) {
-      if (OUT == OUT_CHAIN && mode == (MODE_EXTEND | MODE_FILTER) && closest >= 0) {
+      if (TWO && OUT == OUT_CHAIN && mode == (MODE_EXTEND | MODE_FILTER) && closest >= 0) {
          /* The second tree has been searched: `closest` at t is the nearest primitive the ray meets, toBeat the nearest
           * of all the others.  If those are more than EQUAL_EPSILON apart (and t is clear of the parameters of
           * primitives behind the origin), the reference's walk reports this primitive whatever its order -- nothing else
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          else { mode = MODE_EXTEND; toBeat = -FLT_MAX; t = FLT_MAX; closest = -1; cur = sc.root; sp = 0; }
          return;
       }
-      if (OUT == OUT_CHAIN && (mode & (MODE_KIND | MODE_FILTER)) == (MODE_SHADOW | MODE_FILTER) && closest >= 0) {
+      if (TWO && OUT == OUT_CHAIN && (mode & (MODE_KIND | MODE_FILTER)) == (MODE_SHADOW | MODE_FILTER) && closest >= 0) {
          /* A feeler that has searched the second tree and met something in front of its target.  The reference's walk
           * stops at the first primitive it accepts with a parameter below the target's (kernel.cu:117-121, 128-132) and
           * reports "shadowed" if that parameter is below it by more than EPSILON (kernel.cu:206).  `closest` is in front
@@ -626,7 +631,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       }
       if (COUNT) { max_ray_steps = ray_steps > max_ray_steps ? ray_steps : max_ray_steps; }
       if (!early) plane_scan(sc, c.r, t, closest);
-      if (OUT == OUT_CHAIN && (mode & (MODE_KIND | MODE_FILTER | MODE_VERIFY)) == (MODE_SHADOW | MODE_FILTER) && t < toBeat) {
+      if (TWO && OUT == OUT_CHAIN && (mode & (MODE_KIND | MODE_FILTER | MODE_VERIFY)) == (MODE_SHADOW | MODE_FILTER) && t < toBeat) {
          /* A feeler the filter found nothing for, but with a plane in front of its target: whether that plane counts
           * depends, within EPSILON, on what the reference's walk leaves in t, so that walk is made after all. */
          mode = MODE_SHADOW; cur = sc.root; sp = 0; t = FLT_MAX; closest = -1;
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
    /* Boxes at or beyond this are not entered.  The reference's walk: t.  A closest-hit ray in the second tree looks a
     * little further than its nearest hit so far (RT_LOOK_*); a feeler there carries its limit in t already. */
    auto look_cut = [&]() {
-      const bool widen = OUT == OUT_CHAIN && mode == (MODE_EXTEND | MODE_FILTER);
+      const bool widen = TWO && OUT == OUT_CHAIN && mode == (MODE_EXTEND | MODE_FILTER);
       return widen ? __builtin_fmaf(t, 1.0f + RT_LOOK_REL, RT_LOOK_ABS) : t;
    };
    /* pop deferred siblings until one is still closer than t (kernel.cu:160-186); none left = done.  `cut` is t, or
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          SlabAB sl = slab_ab<VARIANT == 1>(c, na.x, na.y, na.z, na.w, nb.x, nb.y);
          SlabAB sr = slab_ab<VARIANT == 1>(c, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w);
          left = slab_value(sl); right = slab_value(sr);
-         if (sc.filter_root != RT_ROOT_EMPTY && burst_filter) {
+         if (TWO && burst_filter) {
             /* a ray still in the miss filter's tree asks the filter's question of the same two numbers */
             const bool filtering = (mode & MODE_FILTER) != 0;
             float fl = slab_filter_value(sl), fr = slab_filter_value(sr);
@@ -737,7 +742,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       bool goR = r <= l && r < cut;
       bool goL = !goR && l < cut;
       float other = goR ? l : r;
-      if (OUT == OUT_CHAIN && sc.filter_root != RT_ROOT_EMPTY) {
+      if (TWO && OUT == OUT_CHAIN) {
          /* A ray on its way down to the leaf of `closest` (the leaf hangs below node toBeat; nodes are numbered parent,
           * left subtree, right subtree) takes the turn towards it and defers nothing.  The reference's walk takes the
           * same turn here -- at once, or later from its stack -- if the child's box is ahead and starts in front of every
@@ -779,7 +784,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
     * Rays outside the short box test's range do not use the second tree. */
    auto enter_tree = [&]() {
       const int kind_bit = (mode & MODE_KIND) == MODE_EXTEND ? 1 : 2;
-      if (sc.filter_root != RT_ROOT_EMPTY && (sc.filter_kinds & kind_bit) && c.fast && !wave_lit) {
+      if (TWO && (sc.filter_kinds & kind_bit) && c.fast && !wave_lit) {
          cur = sc.filter_root; mode |= MODE_FILTER;
          if (OUT == OUT_CHAIN) {
             if ((mode & MODE_KIND) == MODE_EXTEND) toBeat = FLT_MAX;      /* the nearest of the other primitives, so far */
@@ -1063,7 +1068,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
          wave_par = __ballot(active && c.par != 0) != 0;
          wave_lit = __ballot(active && !c.fast) != 0;
          /* the literal box test has no reading for the second tree's question: a wave that has to use it keeps no ray there */
-         if (wave_lit && active && (mode & MODE_FILTER)) leave_filter();
+         if (TWO && wave_lit && active && (mode & MODE_FILTER)) leave_filter();
          if (COUNT) clk_refill += wall_clock64() - clk0;
       }
       if (m_active == 0) {
@@ -1074,7 +1079,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       /* the box-test variant is the same for a whole burst (the flags only change in a refill): one loop each */
       auto burst_loop = [&](auto variant_tag) {
          /* no ray enters the second tree during a burst (that happens in refills and leaf steps) */
-         burst_filter = __ballot(active && (mode & MODE_FILTER)) != 0;
+         burst_filter = TWO && __ballot(active && (mode & MODE_FILTER)) != 0;
 #pragma unroll 1
          for (int burst = 0; burst < a.node_burst; burst++) {
             bool in_node = cur >= 0;                 /* idle lanes hold RT_CUR_IDLE */
@@ -1105,8 +1110,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             born += 4;                   /* a leaf step weighs about as much as a few node steps */
             top = peek();
             float dist = 0.0f;
-            if (!(OUT == OUT_CHAIN && (mode & MODE_VERIFY))) dist = prim_intersect(sc, ~cur, c.r);
-            if (OUT == OUT_CHAIN && (mode & MODE_VERIFY)) {
+            if (!(TWO && OUT == OUT_CHAIN && (mode & MODE_VERIFY))) dist = prim_intersect(sc, ~cur, c.r);
+            if (TWO && OUT == OUT_CHAIN && (mode & MODE_VERIFY)) {
                /* the way down from the root has arrived: the reference's walk tests this leaf too.  A closest-hit ray's
                 * answer is `closest` at t; on to the planes (the stack is empty, the pop below ends the ray).  A feeler's
                 * walk stops here at the latest, with a parameter that reports "shadowed". */
@@ -1119,7 +1124,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                   t = FLT_MAX; closest = -1; cur = sc.root;
                   if (COUNT) { if (feeler) { n_shadow_cert--; } else { n_cert--; n_unreached++; } }
                }
-            } else if (mode & MODE_FILTER) {
+            } else if (TWO && (mode & MODE_FILTER)) {
                /* still in the filter's tree: does the ray meet this primitive where it could matter? */
                bool shadow = OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND;
                if (COUNT) { if (shadow) nps++; else np++; }
@@ -2100,11 +2105,14 @@ static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs 
    if (!a.stats) a.stats = s->d_stats;
    a.spill = s->d_spill;
    const bool spill = stack_depth(s) > RT_LDS_STACK;
-#define RT_LAUNCH_TRACE(O, C) do { if (spill) hipLaunchKernelGGL((k_trace<O, C, true>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, d, a); \
-                                   else hipLaunchKernelGGL((k_trace<O, C, false>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, d, a); } while (0)
+   const bool two = d.filter_root != RT_ROOT_EMPTY;
+#define RT_LAUNCH_TRACE2(O, C, S) do { if (two) hipLaunchKernelGGL((k_trace<O, C, S, true>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, d, a); \
+                                       else hipLaunchKernelGGL((k_trace<O, C, S, false>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, d, a); } while (0)
+#define RT_LAUNCH_TRACE(O, C) do { if (spill) RT_LAUNCH_TRACE2(O, C, true); else RT_LAUNCH_TRACE2(O, C, false); } while (0)
    if (out_mode == OUT_CHAIN) { if (count) RT_LAUNCH_TRACE(OUT_CHAIN, true); else RT_LAUNCH_TRACE(OUT_CHAIN, false); }
    else { if (count) RT_LAUNCH_TRACE(OUT_HIT, true); else RT_LAUNCH_TRACE(OUT_HIT, false); }
 #undef RT_LAUNCH_TRACE
+#undef RT_LAUNCH_TRACE2
 }
 
 /* device counters of the chunk in flight (rt_scene::d_ctr) */

@@ -14,5 +14,5 @@ with ra.Scene(sd, counters=True, miss_filter=True) as sc:
     for _ in range(2):
         _, ct = sc.render(1920, 1080, spp, abi.RT_COOK_TORRANCE if spp > 1 else abi.RT_PHONG, abi.RT_JITTER_HASH)
 keys = ("rays_total", "rays_shadow", "node_visits", "prim_tests", "node_visits_shadow", "prim_tests_shadow", "wave_node_steps", "wave_leaf_steps",
-        "wave_refills", "max_ray_steps", "hits_certified", "hits_contested", "hits_unreached", "shadows_certified", "ms_trace")
+        "wave_refills", "max_ray_steps", "hits_certified", "hits_contested", "hits_unreached", "shadows_certified", "tie_events_shadow", "ms_trace")
 print(os.environ.get("RT_LIBRARY", "default"), name, {k: ct[k] for k in keys if k in ct}, flush=True)
