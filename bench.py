@@ -136,9 +136,12 @@ def profile_counter(pas, counter):
     (over the passes' timed steps, where the summary tells those apart from the warm-up frames)."""
     path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_summary.json")
     try:
+        # (the kernel has variants; the one the timed steps ran is the one the pass launched most often)
+        best = None
         for kernel, counters in json.load(open(path))[pas].items():
-            if kernel.startswith(DOMINANT):
-                return counters[counter].get("per_launch_timed_steps", counters[counter]["per_launch"])
+            if kernel.startswith(DOMINANT) and (best is None or counters[counter]["launches"] > best["launches"]):
+                best = counters[counter]
+        return best.get("per_launch_timed_steps", best["per_launch"]) if best else None
     except Exception:
         pass
     return None

@@ -85,13 +85,14 @@ def main():
                                 "per_launch_timed_steps": timed_mean(v[2], steps)} for c, v in cs.items()}
                         for k, cs in tab.items() if k.startswith("k_")}
     json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
-    fetch = write = None
-    for k, cs in summary.get("pmc_fetch", {}).items():
-        if DOMINANT in k and "FETCH_SIZE" in cs:
-            fetch = cs["FETCH_SIZE"]["per_launch_timed_steps"]
-    for k, cs in summary.get("pmc_write", {}).items():
-        if DOMINANT in k and "WRITE_SIZE" in cs:
-            write = cs["WRITE_SIZE"]["per_launch_timed_steps"]
+    def dominant(pas, counter):
+        """The counter of the variant of the dominant kernel that the pass launched most often (the timed steps' one)."""
+        best = None
+        for k, cs in summary.get(pas, {}).items():
+            if DOMINANT in k and counter in cs and (best is None or cs[counter]["launches"] > best["launches"]):
+                best = cs[counter]
+        return best["per_launch_timed_steps"] if best else None
+    fetch, write = dominant("pmc_fetch", "FETCH_SIZE"), dominant("pmc_write", "WRITE_SIZE")
     if fetch is not None:
         # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB
         fetch_b = fetch * 1024 * 2
