@@ -381,12 +381,12 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2, MODE_KIND = 3,
 #define RT_SHADOW_ITEM 0x80000000u
 
 #define RT_STEP_CAP (1ULL << 28)
-#define RT_REFILL_IDLE 20   /* pull new rays once this many lanes of the wave are idle */
+#define RT_REFILL_IDLE 24   /* pull new rays once this many lanes of the wave are idle */
 #define RT_CUR_IDLE ((int)0x80000000)
 #define RT_LIST_CAP_FIRST 1024u   /* entries of a wave's list to begin with; doubled when a frame overflows it */
 #define RT_LIST_CAP_MAX 65536u
-#define RT_NODE_BURST 8     /* most node steps between two leaf steps / refill checks */
-#define RT_LEAF_TRIGGER 24  /* lanes waiting at a leaf that end a burst of node steps early */
+#define RT_NODE_BURST 12    /* most node steps between two leaf steps / refill checks */
+#define RT_LEAF_TRIGGER 32  /* lanes waiting at a leaf that end a burst of node steps early */
 #define RT_FETCH_STREAMS 64u /* counters the primaries are handed out through */
 #define RT_CTR_WORDS (8 * ((int)RT_FETCH_STREAMS + 1))   /* 64-bit words of a launch's counters: the streams' (64 bytes apart), then the queue tail */
 #ifndef RT_WAVES_PER_SIMD
