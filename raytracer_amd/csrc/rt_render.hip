@@ -376,8 +376,21 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2, MODE_KIND = 3,
  * within RT_LOOK_ABS + t * RT_LOOK_REL behind it.  It has to know of every primitive within EQUAL_EPSILON of its
  * nearest one; the rest of the margin is allowance for a primitive's computed parameter lying in front of where its
  * (widened) box starts, which rounding in the primitive test could cause. */
+/* How far beyond its target a feeler still looks in the second tree: boxes that start within toBeat * RT_FEELER_REL
+ * behind it.  A primitive counts against a feeler only from EPSILON in front of the target, and stops the reference's
+ * walk from the target's own parameter on; its box starts no later than its true parameter, so this margin (with the
+ * EPSILON in the first case) is what the primitive tests' rounding may use up: 6e-5 of the light's distance, about a
+ * thousand units in the last place.  (It was 2^-10 at first: behind a target 173 away from its light that is 0.17, five
+ * triangles deep into the bunny, and a fifth of its feelers' fetches.) */
+#ifndef RT_FEELER_REL
+#define RT_FEELER_REL (1.0f / 16384.0f)
+#endif
+#ifndef RT_LOOK_ABS
 #define RT_LOOK_ABS 0.05f
+#endif
+#ifndef RT_LOOK_REL
 #define RT_LOOK_REL 0.0078125f
+#endif
 #define RT_SHADOW_ITEM 0x80000000u
 
 #define RT_STEP_CAP (1ULL << 28)
@@ -788,7 +801,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
          cur = sc.filter_root; mode |= MODE_FILTER;
          if (OUT == OUT_CHAIN) {
             if ((mode & MODE_KIND) == MODE_EXTEND) toBeat = FLT_MAX;      /* the nearest of the other primitives, so far */
-            else t = toBeat * (1.0f + 1.0f / 1024.0f);                    /* nothing that starts behind the target can shadow it */
+            else t = toBeat * (1.0f + RT_FEELER_REL);                     /* nothing that starts behind the target can shadow it */
          }
       } else cur = sc.root;
    };
