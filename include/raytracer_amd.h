@@ -185,6 +185,11 @@ typedef struct rt_stats {
    /* likewise: feelers reported "shadowed" from a primitive met in the second tree, clear of the target by more than
     * EQUAL_EPSILON, whose leaf the reference's walk provably reaches (the other shadowed feelers made that walk) */
    uint64_t shadows_certified;
+   /* primary rays that were answered as misses without being traced, a 32x32-pixel tile at a time: every ray through
+    * the tile passes the scene's bounding box by a margin (checked on the host, in double, per camera and frame
+    * size; only for scenes without planes).  They are counted in rays_primary like the rest: the reference traces
+    * each of them (kernel.cu:519-522) to the same result */
+   uint64_t primaries_culled;
 } rt_stats;
 
 typedef struct rt_scene_info {

@@ -440,6 +440,8 @@ struct TraceArgs {
    uint2 *lists;                /* one ring of list_cap (a power of two) entries per wave of the launch: {queue entry | RT_SHADOW_ITEM, light} */
    unsigned list_cap;
    const int *tile_order;       /* when non-null: the order in which the launch's tiles are started (costliest first) */
+   unsigned long long n_fetch;  /* OUT_CHAIN: the first n_fetch slots (in start order) are handed out; the tiles behind them are known to be
+                                 * empty (no ray through them can meet anything) and nothing of them is made, traced or stored.  Otherwise = n */
    StackEntry *spill;           /* SPILL kernels: stack entries beyond the RT_LDS_STACK kept in LDS, [entry - RT_LDS_STACK][lane of the launch] */
    unsigned *dur;               /* when non-null: per queue entry, what the closest-hit ray cost: its own node steps + 4 x its leaf steps */
    unsigned *tile_bounce;       /* when non-null: per tile of the launch (zeroed), set when a primary of the tile spawns a bounce ray */
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
       unsigned long long w = __hip_atomic_load(reinterpret_cast<unsigned long long *>(list + ((list_head + k) & list_mask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return make_uint2((unsigned)w, (unsigned)(w >> 32));
    };
-   const unsigned long long n = a.n;
+   const unsigned long long n = a.n_fetch;       /* slots that are handed out */
    unsigned long long *const stats = a.stats;
    const unsigned long long clock_start = COUNT ? wall_clock64() : 0ULL;     /* 100 MHz */
 #ifdef RT_DEBUG_EXIT_HIST
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
     * after the other, wherever the waves run): 100 000 of them are a millisecond.  So the primaries are handed out
     * through RT_FETCH_STREAMS counters instead of one, queue entries for bounce rays are reserved a range at a time
     * ([res_lo, res_hi)), and a wave sums its statistics in registers and adds them once, when it is done. */
-   const unsigned long long n_patches = (a.n + 63ULL) >> 6;
+   const unsigned long long n_patches = (n + 63ULL) >> 6;
    unsigned stream = (blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) % RT_FETCH_STREAMS;   /* wave-uniform: the stream this wave fetches from */
    unsigned res_lo = 0, res_hi = 0;            /* wave-uniform: OUT_CHAIN, queue entries reserved, not yet used */
    bool res_full = false;                      /* wave-uniform: the queue had no entries left to reserve */
@@ -610,6 +612,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
    unsigned long long clk_refill = 0, clk_node = 0, clk_leaf = 0;   /* COUNT only: 100 MHz ticks this wave spent in each part of its loop */
 #ifdef RT_DEBUG_REFILL_CLK
    unsigned long long dbg_wait = 0, dbg_pre = 0, dbg_c = 0, dbg_d = 0;
+#endif
+#ifdef RT_PROBE_FEELERS
+   bool probe_ref = false;
 #endif
    unsigned n_shadow_cert = 0;                          /* COUNT only: feelers reported "shadowed" from the second tree and one path of the reference's */
    unsigned n_cert = 0, n_rival = 0, n_unreached = 0;   /* COUNT only: how this lane's closest-hit rays left the second tree with a hit */
@@ -654,6 +659,13 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
 #ifdef RT_DEBUG_WAVES
       dbg_fin_clock = wall_clock64(); dbg_fin_start = dbg_ray_start;
       dbg_fin_info = (unsigned long long)(unsigned)mode | ((unsigned long long)(unsigned)(tag & 0xff) << 8) | ((unsigned long long)born << 16);
+#endif
+#ifdef RT_PROBE_FEELERS
+      if (COUNT && OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND) {
+         if (probe_ref) { n_rival++; if (less_than(t, toBeat)) n_cert++; }
+         if (less_than(t, toBeat)) n_unreached++;
+         probe_ref = false;
+      }
 #endif
       if (OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND) {
          /* kernel.cu:206; a feeler that is not shadowed leaves its bit as the launch found it: clear */
@@ -729,6 +741,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
       int2 ch; ch.x = tail.x; ch.y = tail.y;
       StackEntry top = peek();
       if (COUNT) { if (OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND) nvs++; else nv++; }
+#ifdef RT_PROBE_FEELERS
+      if (COUNT && OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND && !(mode & (MODE_FILTER | MODE_VERIFY))) { nts++; probe_ref = true; }
+#endif
       born++;
       float left, right;
       if (VARIANT == 2) {
@@ -1692,6 +1707,12 @@ struct rt_scene {
    std::vector<hipEvent_t> timing_events;   /* spare events of the per-frame timers */
    std::vector<int32_t> prim_ids_host;      /* host copy of DScene::prim_ids */
    std::vector<unsigned> last_cost;         /* the tile costs the current start order was made from */
+   /* Tiles no ray can meet anything through (see cull_tiles): recomputed when the camera or the frame geometry changes */
+   int cull_enabled;                        /* RT_CULL_TILES, default on */
+   bool bounds_ok; double bounds_lo[3], bounds_hi[3];   /* the box every primitive's bounding box lies in */
+   std::vector<unsigned char> tile_live;    /* per selected tile: 1 = has to be traced */
+   long long n_live;
+   float cull_cam[12]; long long cull_key[6];
    /* launch shape and tuning of the traversal kernel, read once per scene from its device and the environment */
    int trace_blocks;        /* workgroups of a full traversal launch: what the device holds at 4 waves per SIMD */
    int refill_idle, node_burst, leaf_trigger, use_tile_order, order_classes;
@@ -1903,6 +1924,17 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    /* a bounce ray needs a material with reflection or refraction above 0 (kernel.cu:360-374) */
    s->can_bounce = false;
    for (int k = 0; k < h.n_materials; k++) if (h.materials[k].refl > 0.0f || h.materials[k].refr > 0.0f) s->can_bounce = true;
+   /* the box all primitives' bounding boxes lie in (for culling whole tiles of primaries, see cull_tiles) */
+   s->bounds_ok = h.n_prims > 0 && h.prim_boxes != nullptr && h.bounds_in_range;
+   s->n_live = -1; memset(s->cull_key, 0, sizeof s->cull_key); memset(s->cull_cam, 0, sizeof s->cull_cam);
+   for (int j = 0; j < 3; j++) { s->bounds_lo[j] = 1e300; s->bounds_hi[j] = -1e300; }
+   for (int k = 0; k < h.n_prims && s->bounds_ok; k++)
+      for (int j = 0; j < 3; j++) {
+         const double lo = h.prim_boxes[6 * (size_t)k + j], hi = h.prim_boxes[6 * (size_t)k + 3 + j];
+         if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi)) { s->bounds_ok = false; break; }
+         if (lo < s->bounds_lo[j]) s->bounds_lo[j] = lo;
+         if (hi > s->bounds_hi[j]) s->bounds_hi[j] = hi;
+      }
 
    if (hipMalloc((void **)&s->d_ctr, RT_CTR_WORDS * sizeof(unsigned long long)) != hipSuccess ||
        hipMalloc((void **)&s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long)) != hipSuccess ||
@@ -2082,6 +2114,7 @@ static void scene_tuning(rt_scene *s)
    s->order_classes = env_int("RT_ORDER_CLASSES", RT_ORDER_CLASSES, false);
    s->order_mean_weight = (double)env_int("RT_ORDER_MEAN_WEIGHT", RT_ORDER_MEAN_WEIGHT, true);
    s->fuse_resolve = env_int("RT_FUSE_RESOLVE", 1, true);
+   s->cull_enabled = env_int("RT_CULL_TILES", 1, true);
    {
       const char *e = getenv("RT_MISS_FILTER");
       s->filter_auto = !(e && *e && atoi(e) == 1 && e[0] == '1');      /* "1": always; unset / "auto": try out ("0" builds no second tree at all) */
@@ -2140,6 +2173,74 @@ static ChunkCtr chunk_ctr(const rt_scene *s, int ring)
    c.next_chain = s->d_ctr;
    c.tail = reinterpret_cast<unsigned *>(s->d_ctr + 8 * RT_FETCH_STREAMS);
    return c;
+}
+
+/* Which of the selected tiles have to be traced at all.
+ *
+ * Every primary ray lies on a line through E = pos - look_dir: sample (u, v) starts at pos + u/2 right + v/2 up and
+ * runs along u/2 right + v/2 up + look_dir (generateCameraRays, kernel.cu:477-498).  The rays of a 32x32-pixel tile
+ * therefore lie inside a pyramid with apex E, spanned by the corner directions of the tile's (u, v) rectangle.  If the
+ * box that holds every primitive's bounding box lies wholly beyond one of the pyramid's four side planes, no ray of
+ * the tile enters any box of the tree, the reference's walk (kernel.cu:136-158) ends at the root and the sample is
+ * the background: nothing of such a tile is made, traced, stored or read.
+ *
+ * The margins are large against the arithmetic they stand in for: the tile's rectangle is widened by a whole sample
+ * spacing and by a thousandth of the image on every side (jitter moves a sample by half a spacing; the float
+ * arithmetic of the ray set-up and of the box tests is good to ~1e-6 of the distances involved), the box by a
+ * thousandth of its size and of its distance from E plus the padding the tree's levels add to their boxes
+ * (BoundingBox.h: 1e-4 per construction).  Computed in double.  Scenes with planes are not culled (planes are
+ * tested for every ray, kernel.cu:189-196). */
+static void cull_tiles(const rt_scene *s, const DCamera &cam, const DGrid &g, int n_sel, std::vector<unsigned char> &live, long long *n_live)
+{
+   live.assign((size_t)n_sel, 1);
+   *n_live = n_sel;
+   if (!s->bounds_ok) return;
+   const double E[3] = {(double)cam.pos.x - cam.look_dir.x, (double)cam.pos.y - cam.look_dir.y, (double)cam.pos.z - cam.look_dir.z};
+   const double R[3] = {cam.right.x, cam.right.y, cam.right.z}, U[3] = {cam.up.x, cam.up.y, cam.up.z};
+   const double Ld[3] = {cam.look_dir.x, cam.look_dir.y, cam.look_dir.z};
+   double lo[3], hi[3], ext = 0.0, dist = 0.0;
+   for (int j = 0; j < 3; j++) {
+      ext = std::max(ext, s->bounds_hi[j] - s->bounds_lo[j]);
+      const double c = 0.5 * (s->bounds_lo[j] + s->bounds_hi[j]) - E[j];
+      dist += c * c;
+   }
+   dist = std::sqrt(dist);
+   const double pad = 1e-3 * (ext + dist) + 2e-4 * (double)(s->host.tree_depth + s->host.filter_depth + 4) + 1e-3;
+   if (!std::isfinite(pad)) return;
+   for (int j = 0; j < 3; j++) { lo[j] = s->bounds_lo[j] - pad; hi[j] = s->bounds_hi[j] + pad; }
+   double corner[8][3];
+   for (int c = 0; c < 8; c++)
+      for (int j = 0; j < 3; j++) corner[c][j] = ((c >> j) & 1 ? hi[j] : lo[j]) - E[j];
+   const double pad_u = 2.0 / (double)g.res_w + 2e-3, pad_v = 2.0 / (double)g.res_h + 2e-3;
+   auto dir = [&](double u, double v, double *d) { for (int j = 0; j < 3; j++) d[j] = 0.5 * u * R[j] + 0.5 * v * U[j] + Ld[j]; };
+   auto cross = [](const double *a, const double *b, double *c) { c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0]; };
+   auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+   long long kept = 0;
+   for (int k = 0; k < n_sel; k++) {
+      const long long tile = (long long)g.tile_first + (long long)k * g.tile_stride;
+      const long long tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+      /* the (u, v) rectangle of the tile's samples: sample X has u = 2 X / res_w - 1 + jitter, |jitter| <= 1/(2 res_w) */
+      const double u0 = 2.0 * (double)(tx * g.ts) / (double)g.res_w - 1.0 - pad_u;
+      const double u1 = 2.0 * (double)((tx + 1) * g.ts) / (double)g.res_w - 1.0 + pad_u;
+      const double v0 = 2.0 * (double)(ty * g.ts) / (double)g.res_h - 1.0 - pad_v;
+      const double v1 = 2.0 * (double)((ty + 1) * g.ts) / (double)g.res_h - 1.0 + pad_v;
+      double d00[3], d10[3], d01[3], d11[3], mid[3];
+      dir(u0, v0, d00); dir(u1, v0, d10); dir(u0, v1, d01); dir(u1, v1, d11); dir(0.5 * (u0 + u1), 0.5 * (v0 + v1), mid);
+      /* the four side planes through E, each through two neighbouring corner directions; inside = the side `mid` is on */
+      const double *edge[4][2] = {{d00, d10}, {d10, d11}, {d11, d01}, {d01, d00}};
+      bool outside = false;
+      for (int e = 0; e < 4 && !outside; e++) {
+         double nrm[3]; cross(edge[e][0], edge[e][1], nrm);
+         const double len = std::sqrt(dot(nrm, nrm)), m = dot(nrm, mid);
+         if (!(len > 0.0) || !std::isfinite(len) || !(std::fabs(m) > 1e-9 * len)) continue;      /* a degenerate camera culls nothing */
+         const double sign = m > 0.0 ? 1.0 : -1.0;
+         bool all_out = true;
+         for (int c = 0; c < 8 && all_out; c++) all_out = sign * dot(nrm, corner[c]) < 0.0;
+         outside = all_out;
+      }
+      if (outside) live[(size_t)k] = 0; else kept++;
+   }
+   *n_live = kept;
 }
 
 /* The frame driver: body of launch_kernel after scene set-up (kernel.cu:735-760), over the tiles this call
@@ -2207,6 +2308,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    }
 
    int attempts = 0;
+   bool culled_frame = false;      /* the frame left tiles out (s->tile_live says which) */
    for (int attempt = 0;; attempt++) {
       memset(&st, 0, sizeof st);
       attempts = attempt + 1;
@@ -2265,7 +2367,33 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          HIP_TRY(hipHostMalloc((void **)&s->h_tile_order, bytes, hipHostMallocDefault));
          s->order_cap = n_sel;
       }
-      const bool have_order = track_cost && s->order_valid && memcmp(key, s->order_key, sizeof key) == 0;
+      bool have_order = track_cost && s->order_valid && memcmp(key, s->order_key, sizeof key) == 0;
+      /* Tiles no ray can meet anything through are left out of the launch: the start order lists the others first, and
+       * only those are handed out.  (Needs what the start order needs, and the per-tile "hit anything" flags that keep
+       * the kernels behind the traversal from reading such a tile.) */
+      bool cull = false;
+      if (track_cost && fuse && s->cull_enabled && sc.n_planes == 0 && s->bounds_ok) {
+         const float camf[12] = {cam.pos.x, cam.pos.y, cam.pos.z, cam.up.x, cam.up.y, cam.up.z, cam.right.x, cam.right.y, cam.right.z,
+                                 cam.look_dir.x, cam.look_dir.y, cam.look_dir.z};
+         if (s->n_live < 0 || memcmp(key, s->cull_key, sizeof key) != 0 || memcmp(camf, s->cull_cam, sizeof camf) != 0) {
+            cull_tiles(s, cam, g, n_sel, s->tile_live, &s->n_live);
+            memcpy(s->cull_key, key, sizeof key); memcpy(s->cull_cam, camf, sizeof camf);
+         }
+         cull = s->n_live < n_sel;
+      }
+      culled_frame = cull;
+      if (cull) {
+         /* live tiles first, in the order they have (image order for a frame without a start order yet) */
+         if (!have_order) { for (long long k = 0; k < n_sel; k++) s->h_tile_order[k] = (int)k; s->order_valid = false; s->order_dirty = true; }
+         std::vector<int> parted((size_t)n_sel);
+         size_t at = 0;
+         for (long long k = 0; k < n_sel; k++) if (s->tile_live[(size_t)s->h_tile_order[k]]) parted[at++] = s->h_tile_order[k];
+         for (long long k = 0; k < n_sel; k++) if (!s->tile_live[(size_t)s->h_tile_order[k]]) parted[at++] = s->h_tile_order[k];
+         if (memcmp(parted.data(), s->h_tile_order, sizeof(int) * (size_t)n_sel) != 0) {
+            memcpy(s->h_tile_order, parted.data(), sizeof(int) * (size_t)n_sel);
+            s->order_dirty = true;
+         }
+      }
 
       /* the caller's stream brackets the frame; the work itself runs on the scene's stream */
       EventPool ev(s->timing_events);
@@ -2294,13 +2422,14 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
                                n_stats, s->d_ctr, ctr.tail, (unsigned)np, track_cost ? s->d_tile_cost : (unsigned *)nullptr, n_cost,
                                fuse ? AT(unsigned, r, o_bounce) : (unsigned *)nullptr, 2 * (int)nb);
             TraceArgs a; memset(&a, 0, sizeof a);
-            a.rays = queue; a.n = (unsigned long long)np; a.hits = hits; a.next = ctr.next_chain;
+            a.rays = queue; a.n = a.n_fetch = (unsigned long long)np; a.hits = hits; a.next = ctr.next_chain;
             a.flag_words = AT(unsigned, r, o_flags); a.flag_stride = flag_stride;
             a.recs = recs; a.tail = ctr.tail; a.cap = cap; a.max_rec = max_rec; a.cam = cam; a.g = g;
             a.points = AT(float4, r, o_points);
             a.lists = s->d_lists; a.list_cap = s->list_cap;
             if (!a.lists || a.list_cap == 0 || (a.list_cap & (a.list_cap - 1)) != 0) { rt_set_error("internal: spawn lists not set up"); return RT_ERR_HIP; }
-            if (have_order) {
+            if (cull) a.n_fetch = (unsigned long long)(s->n_live * per_tile);
+            if (have_order || cull) {
                if (s->order_dirty) {
                   HIP_TRY(hipMemcpyAsync(s->d_tile_order, s->h_tile_order, sizeof(int) * (size_t)n_sel, hipMemcpyHostToDevice, S));
                   s->order_dirty = false;
@@ -2310,7 +2439,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             if (track_cost) { a.dur = AT(unsigned, r, o_dur); a.tile_cost = s->d_tile_cost; }
             if (fuse) { a.tile_bounce = AT(unsigned, r, o_bounce); a.tile_hit = a.tile_bounce + nb; }
             Timer &tm = ev.begin(S, &st.ms_trace);
-            launch_trace(s, OUT_CHAIN, count, a, (unsigned long long)np, lds_bytes, S, filter_kinds);
+            launch_trace(s, OUT_CHAIN, count, a, a.n_fetch, lds_bytes, S, filter_kinds);
             ev.end(tm, S); st.launches_trace++;
          }
          if (view == VIEW_PRIMARY) {
@@ -2413,6 +2542,8 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          for (int c = 0; c < classes; c++) start[(size_t)c + 1] += start[(size_t)c];
          std::vector<int> order((size_t)n_sel);
          for (long long k = 0; k < n_sel; k++) order[(size_t)start[(size_t)cls(costs[(size_t)k])]++] = (int)k;
+         /* tiles that are left out of the launch come last (they cost nothing, but so do traced tiles of background) */
+         if (culled_frame) std::stable_partition(order.begin(), order.end(), [&](int k) { return s->tile_live[(size_t)k] != 0; });
          const bool same = s->order_valid && memcmp(key, s->order_key, sizeof key) == 0 &&
                            memcmp(order.data(), s->h_tile_order, sizeof(int) * (size_t)n_sel) == 0;
          if (!same) {         /* an unchanged order (a still camera) is not uploaded again */
@@ -2433,7 +2564,10 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          long long tile = tile_first + k * tile_stride;
          long long x0 = (tile % tiles_x) * RT_TILE, y0 = (tile / tiles_x) * RT_TILE;
          long long w = p->width - x0 < RT_TILE ? p->width - x0 : RT_TILE, h = p->height - y0 < RT_TILE ? p->height - y0 : RT_TILE;
-         if (w > 0 && h > 0) inside += (unsigned long long)(w * h) * (unsigned long long)p->sample_count;
+         if (w > 0 && h > 0) {
+            inside += (unsigned long long)(w * h) * (unsigned long long)p->sample_count;
+            if (culled_frame && !s->tile_live[(size_t)k]) st.primaries_culled += (unsigned long long)(w * h) * (unsigned long long)p->sample_count;
+         }
       }
       st.rays_primary = inside;
    }
@@ -2640,7 +2774,7 @@ static int trace_rays_in(rt_scene *s, const RayWork &w, int64_t n, const float *
    hipLaunchKernelGGL(k_pack_rays, dim3(grid_for(n)), dim3(RT_BLOCK), 0, S, (const float *)w.raw, to_beat_host ? (const float *)w.beat : (const float *)nullptr,
                       (long long)n, w.queue);
    TraceArgs a; memset(&a, 0, sizeof a);
-   a.rays = w.queue; a.n = (unsigned long long)n; a.hits = w.hits; a.next = w.ctr; a.stats = w.stats;
+   a.rays = w.queue; a.n = a.n_fetch = (unsigned long long)n; a.hits = w.hits; a.next = w.ctr; a.stats = w.stats;
    launch_trace(s, OUT_HIT, false, a, (unsigned long long)n, lds_bytes, S);
    hipLaunchKernelGGL(k_unpack_hits, dim3(grid_for(n)), dim3(RT_BLOCK), 0, S, (const Hit *)w.hits, (long long)n, s->d.prim_ids, s->d.n_prims, w.prim_out, w.t_out);
    HIP_TRY(hipGetLastError());
