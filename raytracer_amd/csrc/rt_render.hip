@@ -393,7 +393,9 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2, MODE_KIND = 3,
 #endif
 #define RT_SHADOW_ITEM 0x80000000u
 
+#ifndef RT_STEP_CAP        /* (a test build may lower it, to turn a wave that would spin into an error) */
 #define RT_STEP_CAP (1ULL << 28)
+#endif
 #define RT_REFILL_IDLE 24   /* pull new rays once this many lanes of the wave are idle */
 #define RT_CUR_IDLE ((int)0x80000000)
 #define RT_LIST_CAP_FIRST 1024u   /* entries of a wave's list to begin with; doubled when a frame overflows it */

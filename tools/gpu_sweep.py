@@ -6,7 +6,7 @@ from raytracer_amd import abi
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "scenes")
 CASES = (("bunny", 4, abi.RT_COOK_TORRANCE), ("balls2", 1, abi.RT_PHONG), ("dragon_large_tris", 1, abi.RT_PHONG))
 scenes = {n: ra.SceneData.load(os.path.join(G, n + ".npz")) for n, _, _ in CASES}
-grid = {"RT_LEAF_TRIGGER": (16, 24, 32), "RT_NODE_BURST": (6, 8, 12), "RT_REFILL_IDLE": (14, 20, 28)}
+grid = {"RT_LEAF_TRIGGER": (24, 32, 40), "RT_NODE_BURST": (8, 12, 16), "RT_REFILL_IDLE": (16, 24, 32)}
 keys = list(grid)
 for combo in itertools.product(*[grid[k] for k in keys]):
     for k, v in zip(keys, combo):
