@@ -1702,7 +1702,8 @@ struct rt_scene {
    long long order_key[6];                /* width, height, samples, tile_first, tile_stride, tiles of the frame the order is for */
    bool can_bounce;                       /* some material reflects or refracts: without one every ray tree is a single node */
    bool order_valid, order_dirty;         /* dirty: h_tile_order differs from what d_tile_order holds */
-   /* The frame's work runs on one internal stream, chunk after chunk; the caller's stream only brackets it. */
+   /* The frame's work runs chunk after chunk on the caller's stream, or (RT_OWN_STREAM=1) on this one with the caller's
+    * stream only bracketing it. */
    hipStream_t chain;
    hipEvent_t ev_begin, ev_end;
    bool streams_ok;
@@ -1721,6 +1722,8 @@ struct rt_scene {
    double order_mean_weight;
    unsigned reserve;        /* queue entries a wave reserves at a time for its bounce rays */
    int fuse_resolve;        /* tiles without bounce rays are shaded by k_resolve itself */
+   int own_stream;          /* RT_OWN_STREAM=1: the frame's kernels run on a stream of the scene's own, bracketed by events on the caller's;
+                             * default: on the caller's stream itself (the hop costs two event waits, ~0.03 ms a frame) */
    /* Which rays start in the second tree is tried out per scene and frame size: frames are the same bytes either way,
     * so the first frames of a size go through the four combinations (closest-hit rays x feelers) and the quickest stays.
     * Scenes whose rays mostly hit something they cannot be certified for (rays inside glass) do better without. */
@@ -2117,6 +2120,7 @@ static void scene_tuning(rt_scene *s)
    s->order_mean_weight = (double)env_int("RT_ORDER_MEAN_WEIGHT", RT_ORDER_MEAN_WEIGHT, true);
    s->fuse_resolve = env_int("RT_FUSE_RESOLVE", 1, true);
    s->cull_enabled = env_int("RT_CULL_TILES", 1, true);
+   s->own_stream = env_int("RT_OWN_STREAM", 0, true);
    {
       const char *e = getenv("RT_MISS_FILTER");
       s->filter_auto = !(e && *e && atoi(e) == 1 && e[0] == '1');      /* "1": always; unset / "auto": try out ("0" builds no second tree at all) */
@@ -2297,7 +2301,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    const long long per_tile = (long long)g.ts * g.ts;
    size_t lds_bytes = 0;
    { int rc = trace_lds_bytes(s, &lds_bytes); if (rc != RT_OK) return rc; }
-   hipStream_t M = s->chain;
+   hipStream_t M = s->own_stream ? s->chain : stream;
 
    /* which rays start in the second tree this frame: the scene's choice, or the next combination of the try-out */
    int filter_kinds = s->filter_choice;
@@ -2397,11 +2401,13 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          }
       }
 
-      /* the caller's stream brackets the frame; the work itself runs on the scene's stream */
+      /* the frame is timed on the caller's stream; the work runs there too unless the scene uses a stream of its own */
       EventPool ev(s->timing_events);
       Timer &t_total = ev.begin(stream, &st.ms_total);
-      HIP_TRY(hipEventRecord(s->ev_begin, stream));
-      HIP_TRY(hipStreamWaitEvent(M, s->ev_begin, 0));
+      if (M != stream) {
+         HIP_TRY(hipEventRecord(s->ev_begin, stream));
+         HIP_TRY(hipStreamWaitEvent(M, s->ev_begin, 0));
+      }
 
       for (long long c = 0; c < n_chunks; c++) {
          const int r = (int)(c % ring);
@@ -2483,14 +2489,16 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       }
 #undef AT
       HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipMemcpyDeviceToHost, M));
-      HIP_TRY(hipEventRecord(s->ev_end, M));
-      HIP_TRY(hipStreamWaitEvent(stream, s->ev_end, 0));
+      if (M != stream) {
+         HIP_TRY(hipEventRecord(s->ev_end, M));
+         HIP_TRY(hipStreamWaitEvent(stream, s->ev_end, 0));
+      }
       ev.end(t_total, stream);
 #ifdef RT_DEBUG_HOST
       dbg_t1 = std::chrono::steady_clock::now();
 #endif
       HIP_TRY(hipStreamSynchronize(stream));
-      HIP_TRY(hipStreamSynchronize(M));
+      if (M != stream) HIP_TRY(hipStreamSynchronize(M));
 #ifdef RT_DEBUG_HOST
       dbg_t2 = std::chrono::steady_clock::now();
 #endif
