@@ -9,7 +9,10 @@ on the reference's own bunny.pov (10 000 flat triangles, one light), the referen
 
 A step is one frame: one persistent traversal launch (primaries, bounces, shadow feelers) -> light sums ->
 combine -> resolve, with the scene and BVH already resident in HBM and the 8-bit frame left in HBM.
-`value` = rays of the frame / wall time per frame, `ms_per_step` = ms per frame.  With N > 1 (one process per
+`value` = rays of the frame / wall time per frame, `ms_per_step` = ms per frame.  The rays of the frame are the ones the
+reference traces for it (kernel.cu:519-522 and the shade tree below); `config.primaries_answered_by_tile` says how many
+of the primaries were answered as misses a whole tile at a time, because no ray through the tile can reach the scene's
+bounding box (the reference answers each of them with its root's box test).  With N > 1 (one process per
 GPU, launched by torch.distributed.run) the frame is sharded by 32x32-pixel tiles, tile k to rank k mod N,
 the scene is replicated, and the compact tile buffers are gathered to rank 0 over RCCL and un-tiled there.
 The gather of frame k overlaps the rendering of frame k + 1 (two part buffers); all K gathers and un-tiles
@@ -307,7 +310,7 @@ def main():
     dt = time.perf_counter() - t0
 
     red_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"
-    rays = torch.tensor([st["rays_total"], st["rays_primary"], st["rays_shadow"], st["rays_reflect"] + st["rays_refract"]],
+    rays = torch.tensor([st["rays_total"], st["rays_primary"], st["rays_shadow"], st["rays_reflect"] + st["rays_refract"], st["primaries_culled"]],
                         dtype=torch.float64, device=red_dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if world > 1:
@@ -389,6 +392,7 @@ def main():
             "config": {"workload": WORKLOAD if (width, height) == (WIDTH, HEIGHT) else WORKLOAD.replace("1920x1080", f"{width}x{height}"),
                        "per_gpu": f"{width * height // world} pixels x {SAMPLES} samples",
                        "rays_per_frame": int(rays[0]), "primary": int(rays[1]), "shadow": int(rays[2]), "bounce": int(rays[3]),
+                       "primaries_answered_by_tile": int(rays[4]),
                        "parallelism": f"tiles{world}", "tile": abi.RT_TILE, "jitter": "hash"},
             # HIP events of the timed steps: the frame on the caller's stream, k_trace on the stream it runs on; the kernels
             # behind it are timed one by one only on the instrumented scene (events between kernels cost stream time)

@@ -2186,7 +2186,8 @@ static ChunkCtr chunk_ctr(const rt_scene *s, int ring)
  * Every primary ray lies on a line through E = pos - look_dir: sample (u, v) starts at pos + u/2 right + v/2 up and
  * runs along u/2 right + v/2 up + look_dir (generateCameraRays, kernel.cu:477-498).  The rays of a 32x32-pixel tile
  * therefore lie inside a pyramid with apex E, spanned by the corner directions of the tile's (u, v) rectangle.  If the
- * box that holds every primitive's bounding box lies wholly beyond one of the pyramid's four side planes, no ray of
+ * box that holds every primitive's bounding box lies wholly beyond one of the pyramid's four side planes (or wholly
+ * behind its apex), no ray of
  * the tile enters any box of the tree, the reference's walk (kernel.cu:136-158) ends at the root and the sample is
  * the background: nothing of such a tile is made, traced, stored or read.
  *
@@ -2243,6 +2244,18 @@ static void cull_tiles(const rt_scene *s, const DCamera &cam, const DGrid &g, in
          bool all_out = true;
          for (int c = 0; c < 8 && all_out; c++) all_out = sign * dot(nrm, corner[c]) < 0.0;
          outside = all_out;
+      }
+      if (!outside) {
+         /* ... or wholly behind the apex: beyond the plane through E across the pyramid's middle direction, which every
+          * direction of the pyramid points away from */
+         bool ahead = dot(mid, mid) > 0.0;
+         const double *cd[4] = {d00, d10, d11, d01};
+         for (int e = 0; e < 4 && ahead; e++) ahead = dot(mid, cd[e]) > 0.0;
+         if (ahead) {
+            bool all_behind = true;
+            for (int c = 0; c < 8 && all_behind; c++) all_behind = dot(mid, corner[c]) < 0.0;
+            outside = all_behind;
+         }
       }
       if (outside) live[(size_t)k] = 0; else kept++;
    }

@@ -89,6 +89,16 @@ def test_random_scenes_near_far_and_inside(seed):
     assert st["primaries_culled"] == 0           # the camera is inside the scene's box: nothing can be left out
 
 
+def test_looking_away_leaves_every_tile_out():
+    """No tile is live: no traversal launch at all, the frame is background, the primaries are still counted."""
+    sd = look_from(synth.random_scene(3, n_planes=0), (0, 1, 40), (0, 1, 100))
+    (f1, s1), (f0, s0) = both(sd, 200, 150, 4, abi.RT_PHONG, n=2)
+    assert f1.tobytes() == f0.tobytes()
+    assert s1["primaries_culled"] == s1["rays_primary"] == 200 * 150 * 4
+    assert s1["rays_total"] == s0["rays_total"] == s1["rays_primary"]
+    assert not f1[..., :3].any()
+
+
 def test_small_objects_on_tile_borders():
     """Spheres a pixel or two across, centred on tile corners of the frame: a tile is left out only if nothing reaches into it."""
     w, h = 512, 384
