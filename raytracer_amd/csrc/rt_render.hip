@@ -2212,13 +2212,20 @@ static void cull_tiles(const rt_scene *s, const DCamera &cam, const DGrid &g, in
       dist += c * c;
    }
    dist = std::sqrt(dist);
-   const double pad = 1e-3 * (ext + dist) + 2e-4 * (double)(s->host.tree_depth + s->host.filter_depth + 4) + 1e-3;
+   /* the float arithmetic of the ray set-up (kernel.cu:493-497) rounds a ray's origin and direction by a few units in
+    * the last place of the camera position's coordinates: a camera far from the origin of the coordinates gets margins
+    * that grow with that */
+   const double pos_ulp = std::max(std::max(std::fabs((double)cam.pos.x), std::fabs((double)cam.pos.y)), std::fabs((double)cam.pos.z)) * (1.0 / 4194304.0);
+   const double pad = 1e-3 * (ext + dist) + 2e-4 * (double)(s->host.tree_depth + s->host.filter_depth + 4) + 1e-3 + 4.0 * pos_ulp * (2.0 + dist);
    if (!std::isfinite(pad)) return;
    for (int j = 0; j < 3; j++) { lo[j] = s->bounds_lo[j] - pad; hi[j] = s->bounds_hi[j] + pad; }
    double corner[8][3];
    for (int c = 0; c < 8; c++)
       for (int j = 0; j < 3; j++) corner[c][j] = ((c >> j) & 1 ? hi[j] : lo[j]) - E[j];
-   const double pad_u = 2.0 / (double)g.res_w + 2e-3, pad_v = 2.0 / (double)g.res_h + 2e-3;
+   const double len_r = std::sqrt(R[0] * R[0] + R[1] * R[1] + R[2] * R[2]), len_u = std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
+   const double pad_u = 2.0 / (double)g.res_w + 2e-3 + (len_r > 0.0 ? 4.0 * pos_ulp / len_r : 0.0);
+   const double pad_v = 2.0 / (double)g.res_h + 2e-3 + (len_u > 0.0 ? 4.0 * pos_ulp / len_u : 0.0);
+   if (!std::isfinite(pad_u) || !std::isfinite(pad_v)) return;
    auto dir = [&](double u, double v, double *d) { for (int j = 0; j < 3; j++) d[j] = 0.5 * u * R[j] + 0.5 * v * U[j] + Ld[j]; };
    auto cross = [](const double *a, const double *b, double *c) { c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0]; };
    auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };

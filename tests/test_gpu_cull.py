@@ -99,6 +99,25 @@ def test_looking_away_leaves_every_tile_out():
     assert not f1[..., :3].any()
 
 
+@pytest.mark.parametrize("shift", [3.0e3, 2.0e4, 1.5e5])
+def test_far_from_the_origin_of_the_coordinates(shift):
+    """Scene and camera moved far out: the float arithmetic of the ray set-up gets coarse (at 1.5e5 a unit in the last
+    place is 1/64), and the margins of the tile test have to grow with it."""
+    sd = synth.random_scene(11, n_spheres=0, n_boxes=0, n_planes=0, n_triangles=40, n_smooth=20)
+    off = np.array([shift, -0.5 * shift, 0.25 * shift], np.float32)
+    for arr in (sd.triangles, sd.smooth_triangles):
+        arr["mod"]["trans"][:] = np.eye(4, dtype=np.float32).reshape(16)
+        arr["mod"]["inv_trans"][:] = np.eye(4, dtype=np.float32).reshape(16)
+        for k in ("p1", "p2", "p3"):
+            arr[k] += off
+    sd.lights["pos"] += off
+    for pos, at in (((0, 1, 9), (0, 0, 0)), ((14, 2, 9), (5, 0, 0)), ((0, 1, 9), (0, 1, 30))):
+        look_from(sd, np.array(pos, np.float32) + off, np.array(at, np.float32) + off)
+        (f1, s1), (f0, s0) = both(sd, 320, 200, 4, abi.RT_PHONG)
+        assert f1.tobytes() == f0.tobytes(), (shift, pos)
+        assert s1["rays_total"] == s0["rays_total"]
+
+
 def test_small_objects_on_tile_borders():
     """Spheres a pixel or two across, centred on tile corners of the frame: a tile is left out only if nothing reaches into it."""
     w, h = 512, 384
