@@ -393,6 +393,7 @@ def main():
                        "per_gpu": f"{width * height // world} pixels x {SAMPLES} samples",
                        "rays_per_frame": int(rays[0]), "primary": int(rays[1]), "shadow": int(rays[2]), "bounce": int(rays[3]),
                        "primaries_answered_by_tile": int(rays[4]),
+                       "Mrays_per_s_without_those": round((rays[0] - rays[4]) * args.steps / dt / 1e6, 2),
                        "parallelism": f"tiles{world}", "tile": abi.RT_TILE, "jitter": "hash"},
             # HIP events of the timed steps: the frame on the caller's stream, k_trace on the stream it runs on; the kernels
             # behind it are timed one by one only on the instrumented scene (events between kernels cost stream time)
