@@ -190,6 +190,10 @@ typedef struct rt_stats {
     * size; only for scenes without planes).  They are counted in rays_primary like the rest: the reference traces
     * each of them (kernel.cu:519-522) to the same result */
    uint64_t primaries_culled;
+   /* shadow feelers that stopped after their own-surface test (kernel.cu:351) because isInShadow's answer cannot change
+    * their point's colour: Phong frames (PhongShader.h:7-25), a light behind the surface whose mirror direction points
+    * away from the eye.  Counted in rays_shadow like the rest (the reference walks its tree for each of them) */
+   uint64_t shadows_unneeded;
 } rt_stats;
 
 typedef struct rt_scene_info {

@@ -247,6 +247,7 @@ static int multi_render(rt_multi *m, const rt_render_params *params, uint8_t *ou
       total.hits_certified += s.hits_certified; total.hits_contested += s.hits_contested; total.hits_unreached += s.hits_unreached;
       total.shadows_certified += s.shadows_certified;
       total.primaries_culled += s.primaries_culled;
+      total.shadows_unneeded += s.shadows_unneeded;
       /* the parts run side by side: a frame takes as long as its slowest part */
       if (s.ms_total > total.ms_total) total.ms_total = s.ms_total;
       if (s.ms_trace > total.ms_trace) total.ms_trace = s.ms_trace;

@@ -119,7 +119,7 @@ struct SpawnRec {
 
 enum { ST_SHADOW_SKIPPED = 0, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES,
        ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
-       ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_CERT_OK, ST_CERT_RIVAL, ST_CERT_UNREACHED, ST_SHADOW_CERT, ST_LEAF_WAIT, ST_NO_RAY, ST_REFILLS, ST_CLK_REFILL, ST_CLK_NODE, ST_CLK_LEAF, ST_CLK_WAVE,
+       ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_CERT_OK, ST_CERT_RIVAL, ST_CERT_UNREACHED, ST_SHADOW_CERT, ST_SHADOW_UNNEEDED, ST_LEAF_WAIT, ST_NO_RAY, ST_REFILLS, ST_CLK_REFILL, ST_CLK_NODE, ST_CLK_LEAF, ST_CLK_WAVE,
        ST_ABORTED, ST_MAX_RAY_STEPS, ST_MAX_LIST, ST_OVERFLOW, ST_LIST_OVERFLOW,
        ST_CLOCK_FIRST_START, ST_CLOCK_LAST_EXIT, ST_CLOCK_EXIT_SUM, ST_WAVES,
 #ifdef RT_DEBUG_EXIT_HIST
@@ -371,7 +371,9 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2, MODE_KIND = 3,
        MODE_FILTER = 4,     /* set while the ray is still in the second tree (see enter_tree below) */
        MODE_VERIFY = 8,     /* set while the ray walks the reference's tree from the root down to one leaf */
        /* a feeler in the second tree, about the primitives it has met in front of its target (see the leaf step) */
-       MODE_BAND = 16 };    /* one within EPSILON of the target: the reference's walk would stop at it and report "lit" */
+       MODE_BAND = 16,      /* one within EPSILON of the target: the reference's walk would stop at it and report "lit" */
+       /* a feeler being set up (MODE_SETUP) whose answer cannot change its point's colour: see TraceArgs::skip_unlit */
+       MODE_UNNEEDED = 32 };
 /* How far beyond the nearest hit so far a closest-hit ray still looks in the second tree: every box that starts
  * within RT_LOOK_ABS + t * RT_LOOK_REL behind it.  It has to know of every primitive within EQUAL_EPSILON of its
  * nearest one; the rest of the margin is allowance for a primitive's computed parameter lying in front of where its
@@ -442,6 +444,14 @@ struct TraceArgs {
    uint2 *lists;                /* one ring of list_cap (a power of two) entries per wave of the launch: {queue entry | RT_SHADOW_ITEM, light} */
    unsigned list_cap;
    const int *tile_order;       /* when non-null: the order in which the launch's tiles are started (costliest first) */
+   /* OUT_CHAIN, Phong frames of scenes with at most 16 lights: a feeler whose answer cannot change the colour of its point
+    * is not traced.  PhongShader.h:7-25 adds, for a light that is not shadowed, (dif * clamp(n.l)) * colour and
+    * (spec * pow(clamp(r.e), 1/rough)) * colour to what a shadowed light gives; where both factors are exactly zero --
+    * the light is behind the surface and its mirror direction points away from the eye -- the two cases are the same
+    * floats, and isInShadow's answer is never looked at.  The spawn stage works the two factors out with the shader's
+    * own expressions and notes the lights that matter in the upper half of the entry's flag word; the feeler of any
+    * other light still makes its own-surface test (kernel.cu:351, which the ray counts depend on) and stops there. */
+   int skip_unlit;
    unsigned long long n_fetch;  /* OUT_CHAIN: the first n_fetch slots (in start order) are handed out; the tiles behind them are known to be
                                  * empty (no ray through them can meet anything) and nothing of them is made, traced or stored.  Otherwise = n */
    StackEntry *spill;           /* SPILL kernels: stack entries beyond the RT_LDS_STACK kept in LDS, [entry - RT_LDS_STACK][lane of the launch] */
@@ -618,6 +628,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
 #ifdef RT_PROBE_FEELERS
    bool probe_ref = false;
 #endif
+   unsigned n_unneeded = 0;                             /* OUT_CHAIN: feelers that stopped after their own-surface test because their answer cannot matter */
    unsigned n_shadow_cert = 0;                          /* COUNT only: feelers reported "shadowed" from the second tree and one path of the reference's */
    unsigned n_cert = 0, n_rival = 0, n_unreached = 0;   /* COUNT only: how this lane's closest-hit rays left the second tree with a hit */
    unsigned n_leafwait = 0, n_noray = 0, n_refills = 0;   /* COUNT only: node steps this lane sat out at a leaf / without a ray; refills of the wave */
@@ -831,6 +842,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
    /* OUT_CHAIN: every lane that finished since the last call writes its spawn record and appends its bounce rays */
    auto spawn_stage = [&]() {
       bool want_refl = false, want_refr = false, shaded = false;
+      float m_dif = 0.0f, m_spec = 0.0f, m_rough = 0.0f;
       bool cont_refl = false, cont_refr = false;      /* this lane goes on with its reflection / refraction ray itself */
       bool front_pushed = false;                      /* wave-uniform: entries were put at the front of the list */
       BounceRays b;
@@ -842,6 +854,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
          const rt_material &m = sc.materials[mat_id];
          float m_refl = m.refl, m_refr = m.refr, m_ior = m.ior;
          out.refl = m_refl; out.alpha = m.alpha;
+         m_dif = m.dif; m_spec = m.spec; m_rough = m.rough;
          if (tag < a.max_rec && (m_refl > 0.0f || m_refr > 0.0f)) {          /* tag = level + 1 */
             b = bounce_rays(sc.prims, sc.xforms, sc.shades, sc.planes, sc.n_prims, c.r.o.x, c.r.o.y, c.r.o.z,
                             c.r.d.x, c.r.d.y, c.r.d.z, closest, t, m_refl, m_refr, m_ior);
@@ -866,7 +879,27 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
                /* ... and its shadow bits start clear (only entries that are shaded have bits anyone reads, so they are
                 * cleared here rather than all at once before the launch; the feelers that set them start in later
                 * refills, behind the fence of a refill that takes list entries) */
-               for (unsigned w = 0; w < a.flag_stride; w++) a.flag_words[(size_t)idx * a.flag_stride + w] = 0u;
+               unsigned first_word = 0u;
+               if (a.skip_unlit) {
+                  /* the lights whose feeler can matter (bit 16 + l), with the expressions of PhongShader.h:12-22 on the
+                   * values the light sums will use (same ray, same t: same floats) */
+                  const F3 nrm = normal_at(sc, closest, c.r, t);
+                  const F3 eye = normalize3(-c.r.d);
+                  for (int l = 0; l < sc.n_lights; l++) {
+                     const rt_dev_light &Lt = sc.lights[l];
+                     const F3 lightDir = normalize3(mk3(Lt.pos[0], Lt.pos[1], Lt.pos[2]) - P);
+                     const float d1 = clamp01(dot3(nrm, lightDir));
+                     const F3 reflect = (2.0f * dot3(lightDir, nrm)) * nrm - lightDir;
+                     const float sp1 = clamp01(dot3(reflect, eye));
+                     /* (dif * d1) * colour is zero when dif * d1 is; spec * pow(s, 1/rough) is zero when spec is (the power
+                      * of a number in [0, 1] with a positive exponent is finite) or when s is (a positive power of zero) */
+                     const bool no_diffuse = (m_dif * d1) == 0.0f;
+                     const bool no_specular = m_rough > 0.0f && (m_spec == 0.0f ? sp1 == sp1 : sp1 == 0.0f);
+                     if (!(no_diffuse && no_specular)) first_word |= 1u << (16 + l);
+                  }
+               }
+               a.flag_words[(size_t)idx * a.flag_stride] = first_word;
+               for (unsigned w = 1; w < a.flag_stride; w++) a.flag_words[(size_t)idx * a.flag_stride + w] = 0u;
             }
             const unsigned cnt = cR + cT;
             if (cnt > res_hi - res_lo && !res_full) {
@@ -1021,6 +1054,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
                const rt_dev_light &Lt = sc.lights[k];
                Ray feeler; feeler.o = mk3(Lt.pos[0], Lt.pos[1], Lt.pos[2]); feeler.d = P - feeler.o;
                if ((int)k + 1 < sc.n_lights) { item.y = k + 1; put_back = true; }     /* same entry, next light */
+               bool unneeded = false;
+               if (a.skip_unlit) {
+                  const unsigned fw = __hip_atomic_load(a.flag_words + (size_t)node * a.flag_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  unneeded = ((fw >> (16u + k)) & 1u) == 0u;
+               }
                c = make_ctx(feeler);
                if (!sc.fast_ok) c.fast = false;
                tag = (int)k; idx = node;
@@ -1029,12 +1067,13 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
                   /* planes are not in the tree: their own-surface test is done here */
                   float param = plane_intersect(sc, hprim - sc.n_prims, feeler);   /* kernel.cu:351 */
                   if (param == -1.0f) n_skipped++;          /* lit, whatever the walk would find: its bit stays clear */
+                  else if (unneeded) n_unneeded++;          /* nobody looks at its bit */
                   else {
                      toBeat = param; mode = MODE_SHADOW; enter_tree(); active = true;
                      if (cur == RT_ROOT_EMPTY) finish(false);
                   }
                } else {
-                  mode = MODE_SETUP; cur = ~hprim; toBeat = -FLT_MAX; active = true;
+                  mode = unneeded ? (MODE_SETUP | MODE_UNNEEDED) : MODE_SETUP; cur = ~hprim; toBeat = -FLT_MAX; active = true;
                }
             } else {
                bool have = false;
@@ -1187,11 +1226,12 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
                   if (above_zero(dist)) leave_filter();     /* the reference's walk, from its root */
                   else tested = true;                       /* take stays false: on to the next deferred box */
                }
-            } else if (OUT == OUT_CHAIN && mode == MODE_SETUP) {
+            } else if (OUT == OUT_CHAIN && (mode & ~MODE_UNNEEDED) == MODE_SETUP) {
                /* the feeler against its own surface (kernel.cu:351).  A feeler that misses it (-1) can never be
                 * reported shadowed: isFloatLessThan(closest, -1) is false for every accepted t.  The reference
                 * still walks the tree for it; that walk is skipped here and counted separately. */
                if (dist == -1.0f) { n_skipped++; active = false; cur = RT_CUR_IDLE; }
+               else if (mode & MODE_UNNEEDED) { n_unneeded++; active = false; cur = RT_CUR_IDLE; }      /* its bit stays clear; nobody looks at it */
                else {
                   toBeat = dist; mode = MODE_SHADOW; enter_tree();
                   if (cur == RT_ROOT_EMPTY) finish(false);
@@ -1255,7 +1295,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
       /* what is left of the reserved queue entries reads as a miss (the light sums run over every entry below the tail) */
       for (unsigned u = res_lo + lane; u < res_hi; u += 64) { Hit h; h.prim = -1; h.t = FLT_MAX; a.hits[u] = h; }
       for (int o = 32; o > 0; o >>= 1) n_skipped += __shfl_xor(n_skipped, o);
+      for (int o = 32; o > 0; o >>= 1) n_unneeded += __shfl_xor(n_unneeded, o);
       if (lane == 0) {
+         if (n_unneeded) stat_add(stats, ST_SHADOW_UNNEEDED, (unsigned long long)n_unneeded);
          if (list_peak) atomicMax(&stats[ST_MAX_LIST * RT_STAT_REPL], (unsigned long long)list_peak);
          if (n_skipped) stat_add(stats, ST_SHADOW_SKIPPED, (unsigned long long)n_skipped);
          if (w_shaded) stat_add(stats, ST_SHADE_NODES, (unsigned long long)w_shaded);
@@ -1722,6 +1764,8 @@ struct rt_scene {
    double order_mean_weight;
    unsigned reserve;        /* queue entries a wave reserves at a time for its bounce rays */
    int fuse_resolve;        /* tiles without bounce rays are shaded by k_resolve itself */
+   int skip_unlit;          /* RT_SKIP_UNLIT (default on): see TraceArgs::skip_unlit */
+   bool lights_finite;      /* every light's colour is a finite number */
    int own_stream;          /* RT_OWN_STREAM=1: the frame's kernels run on a stream of the scene's own, bracketed by events on the caller's;
                              * default: on the caller's stream itself (the hop costs two event waits, ~0.03 ms a frame) */
    /* Which rays start in the second tree is tried out per scene and frame size: frames are the same bytes either way,
@@ -1929,6 +1973,8 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    /* a bounce ray needs a material with reflection or refraction above 0 (kernel.cu:360-374) */
    s->can_bounce = false;
    for (int k = 0; k < h.n_materials; k++) if (h.materials[k].refl > 0.0f || h.materials[k].refr > 0.0f) s->can_bounce = true;
+   s->lights_finite = true;
+   for (int k = 0; k < h.n_lights; k++) for (int j = 0; j < 3; j++) if (!std::isfinite(h.lights[k].clr[j])) s->lights_finite = false;
    /* the box all primitives' bounding boxes lie in (for culling whole tiles of primaries, see cull_tiles) */
    s->bounds_ok = h.n_prims > 0 && h.prim_boxes != nullptr && h.bounds_in_range;
    s->n_live = -1; memset(s->cull_key, 0, sizeof s->cull_key); memset(s->cull_cam, 0, sizeof s->cull_cam);
@@ -2120,6 +2166,7 @@ static void scene_tuning(rt_scene *s)
    s->order_mean_weight = (double)env_int("RT_ORDER_MEAN_WEIGHT", RT_ORDER_MEAN_WEIGHT, true);
    s->fuse_resolve = env_int("RT_FUSE_RESOLVE", 1, true);
    s->cull_enabled = env_int("RT_CULL_TILES", 1, true);
+   s->skip_unlit = env_int("RT_SKIP_UNLIT", 1, true);
    s->own_stream = env_int("RT_OWN_STREAM", 0, true);
    {
       const char *e = getenv("RT_MISS_FILTER");
@@ -2457,6 +2504,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
             a.lists = s->d_lists; a.list_cap = s->list_cap;
             if (!a.lists || a.list_cap == 0 || (a.list_cap & (a.list_cap - 1)) != 0) { rt_set_error("internal: spawn lists not set up"); return RT_ERR_HIP; }
             if (cull) a.n_fetch = (unsigned long long)(s->n_live * per_tile);
+            a.skip_unlit = (s->skip_unlit && p->shading == RT_PHONG && L >= 1 && L <= 16 && s->lights_finite) ? 1 : 0;
             if (have_order || cull) {
                if (s->order_dirty) {
                   HIP_TRY(hipMemcpyAsync(s->d_tile_order, s->h_tile_order, sizeof(int) * (size_t)n_sel, hipMemcpyHostToDevice, S));
@@ -2617,6 +2665,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    st.hits_certified = sum_stat(s->h_stats, ST_CERT_OK); st.hits_contested = sum_stat(s->h_stats, ST_CERT_RIVAL);
    st.hits_unreached = sum_stat(s->h_stats, ST_CERT_UNREACHED);
    st.shadows_certified = sum_stat(s->h_stats, ST_SHADOW_CERT);
+   st.shadows_unneeded = sum_stat(s->h_stats, ST_SHADOW_UNNEEDED);
    {
       double w = (double)sum_stat(s->h_stats, ST_CLK_WAVE);
       st.wave_time_refill = w > 0 ? (float)((double)sum_stat(s->h_stats, ST_CLK_REFILL) / w) : 0.0f;

@@ -1,0 +1,101 @@
+"""Feelers whose answer cannot change their point's colour are not traced: no byte changes.
+
+In a Phong frame a light that is behind the surface, with its mirror direction pointing away from the eye, adds exactly
+zero to a point whether it is shadowed or not (PhongShader.h:7-25), so isInShadow's answer for it is never looked at.
+Such a feeler makes its own-surface test (the ray counts depend on it) and stops.  RT_SKIP_UNLIT=0 turns that off
+(read when a scene is created): frames, per-sample colours and every ray count must be the same either way.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as ra
+from raytracer_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes")
+COUNTS = ("rays_total", "rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "shade_nodes", "shadow_skipped")
+
+
+def scene_with(skip, sd, **kw):
+    old = os.environ.get("RT_SKIP_UNLIT")
+    os.environ["RT_SKIP_UNLIT"] = "1" if skip else "0"
+    try:
+        return ra.Scene(sd, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("RT_SKIP_UNLIT", None)
+        else:
+            os.environ["RT_SKIP_UNLIT"] = old
+
+
+def both(sd, w, h, spp, shading, n=1):
+    out = []
+    for skip in (True, False):
+        with scene_with(skip, sd) as sc:
+            for _ in range(n):
+                frame, st = sc.render(w, h, spp, shading, abi.RT_JITTER_HASH, 9)
+            rgb, _ = sc.render_samples(w, h, spp, shading, abi.RT_JITTER_HASH, 9)
+            out.append((frame, rgb, st))
+    return out
+
+
+@pytest.mark.parametrize("name", ["balls2", "bunny", "dragon_large_tris", "iceBot", "valentine", "recurse_simp2", "cornell", "simple_refract", "blitzcrank"])
+def test_fixture_scenes_same_bytes_and_counts(name):
+    path = os.path.join(G, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip("no such fixture scene")
+    sd = ra.SceneData.load(path)
+    (f1, c1, s1), (f0, c0, s0) = both(sd, 333, 257, 1, abi.RT_PHONG, n=2)
+    assert f1.tobytes() == f0.tobytes()
+    assert np.array_equal(np.asarray(c1) == 0, np.asarray(c0) == 0) and np.array_equal(np.abs(c1), np.abs(c0))     # same floats (a zero may change its sign)
+    assert s0["shadows_unneeded"] == 0
+    for k in COUNTS:
+        assert s1[k] == s0[k], k
+
+
+def test_balls2_skips_some_of_its_feelers():
+    sd = ra.SceneData.load(os.path.join(G, "balls2.npz"))
+    (f1, _, s1), (f0, _, s0) = both(sd, 480, 270, 1, abi.RT_PHONG)
+    assert f1.tobytes() == f0.tobytes()
+    assert s1["shadows_unneeded"] > s1["rays_shadow"] // 20
+
+
+def test_cook_torrance_skips_nothing():
+    """CookTorranceShader.h:7-46 has no clamp on its specular term: a light behind the surface still adds to the colour."""
+    sd = ra.SceneData.load(os.path.join(G, "balls2.npz"))
+    with scene_with(True, sd) as sc:
+        _, st = sc.render(240, 135, 1, abi.RT_COOK_TORRANCE, abi.RT_JITTER_HASH, 9)
+    assert st["shadows_unneeded"] == 0
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_scenes(seed):
+    """Every primitive class, random finishes (specular from 0 up, a third reflecting, a fifth refracting), two lights."""
+    sd = synth.random_scene(300 + seed)
+    if seed % 3 == 0:
+        for name in ("spheres", "triangles", "boxes", "smooth_triangles", "planes"):
+            getattr(sd, name)["mod"]["mat"]["spec"] = 0.0
+    (f1, c1, s1), (f0, c0, s0) = both(sd, 200, 150, 4 if seed & 1 else 1, abi.RT_PHONG)
+    assert f1.tobytes() == f0.tobytes()
+    assert np.array_equal(np.abs(c1), np.abs(c0))
+    assert s1["shadows_unneeded"] > 0
+    for k in COUNTS:
+        assert s1[k] == s0[k], k
+
+
+def test_seventeen_lights_skip_nothing():
+    sd = synth.random_scene(5, n_lights=17)
+    (f1, _, s1), (f0, _, s0) = both(sd, 160, 120, 1, abi.RT_PHONG)
+    assert f1.tobytes() == f0.tobytes()
+    assert s1["shadows_unneeded"] == 0
+
+
+def test_sixteen_lights():
+    sd = synth.random_scene(6, n_lights=16)
+    (f1, _, s1), (f0, _, s0) = both(sd, 160, 120, 1, abi.RT_PHONG)
+    assert f1.tobytes() == f0.tobytes()
+    assert s1["shadows_unneeded"] > 0
+    for k in COUNTS:
+        assert s1[k] == s0[k], k
