@@ -20,7 +20,7 @@ COUNTS = ("rays_total", "rays_primary", "rays_shadow", "rays_reflect", "rays_ref
 
 def scene_with(skip, sd, **kw):
     old = os.environ.get("RT_SKIP_UNLIT")
-    os.environ["RT_SKIP_UNLIT"] = "1" if skip else "0"
+    os.environ["RT_SKIP_UNLIT"] = "1000" if skip else "0"      # the number of lights up to which it is used (16 by default)
     try:
         return ra.Scene(sd, **kw)
     finally:
@@ -85,15 +85,17 @@ def test_random_scenes(seed):
         assert s1[k] == s0[k], k
 
 
-def test_seventeen_lights_skip_nothing():
-    sd = synth.random_scene(5, n_lights=17)
-    (f1, _, s1), (f0, _, s0) = both(sd, 160, 120, 1, abi.RT_PHONG)
+def test_more_lights_than_a_flag_word_holds():
+    sd = synth.random_scene(5, n_lights=70)
+    (f1, _, s1), (f0, _, s0) = both(sd, 120, 90, 1, abi.RT_PHONG)
     assert f1.tobytes() == f0.tobytes()
-    assert s1["shadows_unneeded"] == 0
+    assert s1["shadows_unneeded"] > 0
+    for k in COUNTS:
+        assert s1[k] == s0[k], k
 
 
-def test_sixteen_lights():
-    sd = synth.random_scene(6, n_lights=16)
+def test_thirty_two_lights():
+    sd = synth.random_scene(6, n_lights=32)
     (f1, _, s1), (f0, _, s0) = both(sd, 160, 120, 1, abi.RT_PHONG)
     assert f1.tobytes() == f0.tobytes()
     assert s1["shadows_unneeded"] > 0

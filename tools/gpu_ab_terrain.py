@@ -9,4 +9,4 @@ with ra.Scene(sd, fast_bvh=True) as sc:
     for i in range(4):
         _, st = sc.render(1920, 1080, 4, abi.RT_PHONG, abi.RT_JITTER_HASH)
         ts.append(st["ms_total"])
-print(os.environ.get("RT_LIBRARY", "default"), "terrain 1080p 4spp ms:", " ".join(f"{t:.1f}" for t in ts), flush=True)
+print(os.environ.get("RT_LIBRARY", "default"), "terrain 1080p 4spp ms:", " ".join(f"{t:.1f}" for t in ts), "; feelers", st["rays_shadow"], "of them stopped after their own-surface test", st["shadows_unneeded"], flush=True)
