@@ -286,6 +286,13 @@ int rt_render_device(const rt_scene *scene, const rt_render_params *params,
 /* Number of tiles a (first, stride) selection covers for a width x height frame. */
 int rt_tile_count(int width, int height, int tile_first, int tile_stride);
 
+/* Which of the selected tiles a frame of these parameters would trace: live[k] = 1 for selection entry k
+ * (k < rt_tile_count()), 0 for a tile that is left out of the launch because no primary ray through it can reach the
+ * box that holds every primitive's bounding box (scenes without planes; see rt_stats.primaries_culled).  No
+ * counterpart in the reference, which traces every sample (kernel.cu:519-522); a host computation, for callers and
+ * tests that want to know what a frame skips.  Works on scenes made with rt_scene_create_host too. */
+int rt_tiles_live(const rt_scene *scene, const rt_render_params *params, uint8_t *live, int n);
+
 /* Scatter `n_parts` compact tile buffers (RT_OUT_TILES, part p made with
  * tile_first = p, tile_stride = n_parts), laid back to back in `tiles_dev`
  * with `part_stride_bytes` between parts, into a row-major device frame. */

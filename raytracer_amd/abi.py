@@ -114,7 +114,7 @@ class SceneInfo(C.Structure):
 # every symbol include/raytracer_amd.h and include/raytracer_tokens.h declare
 EXPORTED_SYMBOLS = [
     "rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_create_host", "rt_scene_destroy", "rt_scene_get_info",
-    "rt_scene_get_bvh", "rt_scene_set_camera", "rt_render", "rt_render_device", "rt_tile_count",
+    "rt_scene_get_bvh", "rt_scene_set_camera", "rt_render", "rt_render_device", "rt_tile_count", "rt_tiles_live",
     "rt_multi_create", "rt_multi_destroy", "rt_multi_device_count", "rt_multi_set_camera", "rt_multi_render", "rt_multi_render_device",
     "rt_untile_device", "rt_trace_primary", "rt_trace_rays", "rt_trace_rays_static", "rt_render_samples",
     "rt_parse_pov", "rt_scene_desc_free", "rt_load_bmp", "rt_write_tga", "launch_kernel",
@@ -147,6 +147,7 @@ def load_library(path=None):
     lib.rt_render.argtypes = [vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]
     lib.rt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     lib.rt_tile_count.argtypes = [C.c_int] * 4
+    lib.rt_tiles_live.argtypes = [vp, C.POINTER(RenderParams), vp, C.c_int]
     lib.rt_untile_device.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.rt_trace_primary.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
     lib.rt_trace_rays.argtypes = [vp, i64c, vp, vp, vp, vp]

@@ -132,6 +132,15 @@ class Scene:
             getattr(cam, k)[:] = [float(x) for x in v]
         _check(self._lib, self._lib.rt_scene_set_camera(self._h, C.byref(cam)))
 
+    def tiles_live(self, width, height, sample_count=1, tile_first=0, tile_stride=1):
+        """Per selected tile: 1 if a frame of this size traces it, 0 if it is left out of the launch (no ray through
+        it can reach the scene's bounding box).  A host computation; works on host-only scenes."""
+        p = make_params(width, height, sample_count, PHONG, abi.RT_JITTER_HASH, 0, 0, tile_first, tile_stride)
+        n = self._lib.rt_tile_count(width, height, tile_first, tile_stride)
+        live = np.zeros(max(n, 1), np.uint8)
+        _check(self._lib, self._lib.rt_tiles_live(self._h, C.byref(p), live.ctypes.data, n))
+        return live[:n]
+
     # ----------------------------------------------------------------- render
     def render(self, width, height, sample_count=1, shading=PHONG, jitter=abi.RT_JITTER_HASH, seed=0, max_recurse=0,
                tile_first=0, tile_stride=1):

@@ -1836,6 +1836,22 @@ static int env_int(const char *name, int fallback, bool allow_zero);
 static int stack_depth(const rt_scene *s);
 static int scratch_address(int device, char **out);
 
+/* the box all primitives' bounding boxes lie in (for leaving whole tiles of primaries out of a launch, see cull_tiles) */
+static void scene_bounds(rt_scene *s)
+{
+   const rt_flat_scene &h = s->host;
+   s->bounds_ok = h.n_prims > 0 && h.prim_boxes != nullptr && h.bounds_in_range;
+   s->n_live = -1; memset(s->cull_key, 0, sizeof s->cull_key); memset(s->cull_cam, 0, sizeof s->cull_cam);
+   for (int j = 0; j < 3; j++) { s->bounds_lo[j] = 1e300; s->bounds_hi[j] = -1e300; }
+   for (int k = 0; k < h.n_prims && s->bounds_ok; k++)
+      for (int j = 0; j < 3; j++) {
+         const double lo = h.prim_boxes[6 * (size_t)k + j], hi = h.prim_boxes[6 * (size_t)k + 3 + j];
+         if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi)) { s->bounds_ok = false; break; }
+         if (lo < s->bounds_lo[j]) s->bounds_lo[j] = lo;
+         if (hi > s->bounds_hi[j]) s->bounds_hi[j] = hi;
+      }
+}
+
 extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
 {
    if (!desc || !out) { rt_set_error("rt_scene_create_host: null argument"); return RT_ERR_BAD_ARGUMENT; }
@@ -1853,6 +1869,8 @@ extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
    int st = rt_flatten_scene(desc, &s->host);
    if (st != RT_OK) { delete s; return st; }
    s->ms_build_host = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+   s->cull_enabled = 1;
+   scene_bounds(s);
    *out = s;
    return RT_OK;
 }
@@ -1976,17 +1994,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    for (int k = 0; k < h.n_materials; k++) if (h.materials[k].refl > 0.0f || h.materials[k].refr > 0.0f) s->can_bounce = true;
    s->lights_finite = true;
    for (int k = 0; k < h.n_lights; k++) for (int j = 0; j < 3; j++) if (!std::isfinite(h.lights[k].clr[j])) s->lights_finite = false;
-   /* the box all primitives' bounding boxes lie in (for culling whole tiles of primaries, see cull_tiles) */
-   s->bounds_ok = h.n_prims > 0 && h.prim_boxes != nullptr && h.bounds_in_range;
-   s->n_live = -1; memset(s->cull_key, 0, sizeof s->cull_key); memset(s->cull_cam, 0, sizeof s->cull_cam);
-   for (int j = 0; j < 3; j++) { s->bounds_lo[j] = 1e300; s->bounds_hi[j] = -1e300; }
-   for (int k = 0; k < h.n_prims && s->bounds_ok; k++)
-      for (int j = 0; j < 3; j++) {
-         const double lo = h.prim_boxes[6 * (size_t)k + j], hi = h.prim_boxes[6 * (size_t)k + 3 + j];
-         if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi)) { s->bounds_ok = false; break; }
-         if (lo < s->bounds_lo[j]) s->bounds_lo[j] = lo;
-         if (hi > s->bounds_hi[j]) s->bounds_hi[j] = hi;
-      }
+   scene_bounds(s);
 
    if (hipMalloc((void **)&s->d_ctr, RT_CTR_WORDS * sizeof(unsigned long long)) != hipSuccess ||
        hipMalloc((void **)&s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long)) != hipSuccess ||
@@ -2315,6 +2323,28 @@ static void cull_tiles(const rt_scene *s, const DCamera &cam, const DGrid &g, in
       if (outside) live[(size_t)k] = 0; else kept++;
    }
    *n_live = kept;
+}
+
+extern "C" int rt_tiles_live(const rt_scene *s, const rt_render_params *p, uint8_t *live, int n)
+{
+   if (!s || !p || !live) { rt_set_error("rt_tiles_live: null argument"); return RT_ERR_BAD_ARGUMENT; }
+   if (p->width <= 0 || p->height <= 0 || p->sample_count <= 0) { rt_set_error("rt_tiles_live: non-positive size"); return RT_ERR_BAD_ARGUMENT; }
+   const int sroot = isqrt_trunc(p->sample_count);
+   if (sroot * sroot != p->sample_count) { rt_set_error("Invalid sample count: %d. Sample count for anti aliasing must have an integer square root", p->sample_count); return RT_ERR_BAD_SAMPLE_COUNT; }
+   if (!s->has_camera) { rt_set_error("scene has no camera"); return RT_ERR_NO_CAMERA; }
+   const int tile_stride = p->tile_stride > 0 ? p->tile_stride : 1;
+   const int n_sel = rt_tile_count(p->width, p->height, p->tile_first, tile_stride);
+   if (n < n_sel) { rt_set_error("rt_tiles_live: room for %d tiles, the selection has %d", n, n_sel); return RT_ERR_BAD_ARGUMENT; }
+   DGrid g; memset(&g, 0, sizeof g);
+   g.width = p->width; g.height = p->height; g.sroot = sroot;
+   g.res_w = p->width * sroot; g.res_h = p->height * sroot;
+   g.tiles_x = (p->width + RT_TILE - 1) / RT_TILE;
+   g.tile_first = p->tile_first; g.tile_stride = tile_stride; g.ts = RT_TILE * sroot;
+   std::vector<unsigned char> v((size_t)(n_sel > 0 ? n_sel : 0), 1);
+   long long kept = n_sel;
+   if (n_sel > 0 && s->cull_enabled && s->host.n_planes == 0 && s->bounds_ok) cull_tiles(s, make_camera(s->camera), g, n_sel, v, &kept);
+   for (int k = 0; k < n_sel; k++) live[k] = v[(size_t)k];
+   return RT_OK;
 }
 
 /* The frame driver: body of launch_kernel after scene set-up (kernel.cu:735-760), over the tiles this call
