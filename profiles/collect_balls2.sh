@@ -1,6 +1,6 @@
 #!/bin/bash
-# Counter passes of the balls2 1080p frame (the frame the previous round's profiles were taken on), for a
-# like-for-like before/after of the traversal kernel.  Run from the repo root through gpurun.
+# Counter passes of the balls2 1080p frame (the frame the first profiles of the traversal kernel were taken on), for a
+# like-for-like before/after of that kernel.  Run from the repo root through gpurun.
 set -e -o pipefail
 TAG=${1:-r02}
 OUT=gpurun_out/prof_${TAG}_balls2
