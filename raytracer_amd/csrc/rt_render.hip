@@ -2244,9 +2244,8 @@ static ChunkCtr chunk_ctr(const rt_scene *s, int ring)
  * runs along u/2 right + v/2 up + look_dir (generateCameraRays, kernel.cu:477-498).  The rays of a 32x32-pixel tile
  * therefore lie inside a pyramid with apex E, spanned by the corner directions of the tile's (u, v) rectangle.  If the
  * box that holds every primitive's bounding box lies wholly beyond one of the pyramid's four side planes (or wholly
- * behind its apex), no ray of
- * the tile enters any box of the tree, the reference's walk (kernel.cu:136-158) ends at the root and the sample is
- * the background: nothing of such a tile is made, traced, stored or read.
+ * behind its apex), no ray of the tile enters any box of the tree, the reference's walk (kernel.cu:136-158) ends at
+ * the root and the sample is the background: nothing of such a tile is made, traced, stored or read.
  *
  * The margins are large against the arithmetic they stand in for: the tile's rectangle is widened by a whole sample
  * spacing and by a thousandth of the image on every side (jitter moves a sample by half a spacing; the float
