@@ -193,41 +193,30 @@ def secondary_frames(ra, abi, torch, stream):
     return out
 
 
-def frames_in_flight(ra, torch, sd, params, rays_per_frame, n_scenes=2, frames=60):
-    """Throughput of a frame sequence with `n_scenes` frames in flight: one replica of the scene per frame in flight,
-    each rendered from a host thread of its own on a stream of its own, so that a frame's last waves and its resolve
-    pass overlap the next frame's first waves.  Outside the timed region; every frame is a whole frame."""
-    import threading
-    scenes = [ra.Scene(sd, device=0) for _ in range(n_scenes)]
-    streams = [torch.cuda.Stream() for _ in range(n_scenes)]
-    bufs = [torch.zeros(params.width * params.height * 4, dtype=torch.uint8, device="cuda") for _ in range(n_scenes)]
-    try:
-        for sc, st, b in zip(scenes, streams, bufs):
-            for _ in range(8):                       # first frame, second-tree try-out, start order
-                sc.render_device(params, b.data_ptr(), st.cuda_stream)
+def frames_in_flight(ra, torch, sd, params, rays_per_frame, in_flight=2, frames=60):
+    """Throughput of a frame sequence with `in_flight` frames in flight (rt_sequence_*: a replica of the scene, a
+    stream and a host thread per frame in flight), so that a frame's last waves and its resolve pass overlap the next
+    frame's first waves.  Outside the timed region; every frame is a whole frame."""
+    bufs = [torch.zeros(params.width * params.height * 4, dtype=torch.uint8, device="cuda") for _ in range(in_flight)]
+    with ra.Sequence(sd, device=0, frames_in_flight=in_flight) as seq:
+        def run(n):
+            for k in range(n):
+                if k >= in_flight:
+                    seq.wait()
+                seq.submit(params, bufs[k % in_flight].data_ptr())
+            for _ in range(min(n, in_flight)):
+                seq.wait()
+        run(8 * in_flight)                      # per replica: first frame, second-tree try-out, start order
         torch.cuda.synchronize()
-
-        def work(i):
-            for _ in range(frames // n_scenes):
-                scenes[i].render_device(params, bufs[i].data_ptr(), streams[i].cuda_stream)
-
         t0 = time.perf_counter()
-        threads = [threading.Thread(target=work, args=(i,)) for i in range(n_scenes)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        run(frames)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    finally:
-        for sc in scenes:
-            sc.close()
-    done = (frames // n_scenes) * n_scenes
-    return {"frames_in_flight": n_scenes, "frames": done, "ms_per_frame": round(dt / done * 1e3, 4),
-            "Mrays_per_s": round(rays_per_frame * done / dt / 1e6, 1),
-            "note": "a sequence of whole headline frames with two in flight (two replicas of the scene, a host thread and a stream "
-                    "each): the end of one frame's traversal launch, where few waves are left, and its resolve pass overlap the start "
-                    "of the next frame's; `value` above is measured with one frame in flight"}
+    return {"frames_in_flight": in_flight, "frames": frames, "ms_per_frame": round(dt / frames * 1e3, 4),
+            "Mrays_per_s": round(rays_per_frame * frames / dt / 1e6, 1),
+            "note": "a sequence of whole headline frames with two in flight (rt_sequence_*: two replicas of the scene, a host thread "
+                    "and a stream each): the end of one frame's traversal launch, where few waves are left, and its resolve pass "
+                    "overlap the start of the next frame's; `value` above is measured with one frame in flight"}
 
 
 def end_to_end(ra, abi, first_ms, steady_ms):

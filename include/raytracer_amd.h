@@ -316,6 +316,26 @@ int rt_multi_render(rt_multi *multi, const rt_render_params *params, uint8_t *ou
 /* the same, the frame left in memory of the first device (out_rgba_dev: width*height*4 bytes there) */
 int rt_multi_render_device(rt_multi *multi, const rt_render_params *params, void *out_rgba_dev, rt_stats *stats);
 
+/* ---- a frame sequence with several frames in flight --------------------- */
+/* The reference renders one frame per process (raytrace.cpp:18-56) and has nothing like this.  A caller that renders
+ * a sequence of frames of one scene (a camera path) keeps `frames_in_flight` replicas of the scene on `device`, each
+ * with a stream and a host thread of its own; frames are dealt to the replicas in turn, so that the end of one frame
+ * (the last waves of its traversal launch, its resolve pass, the host's wake-up) overlaps the start of the next.
+ * Every frame is a whole rt_render_device frame: the same bytes and statistics.
+ *   rt_sequence_submit  queues the next frame and returns at once: `params` and `camera` (NULL = the camera the replica
+ *                       has: the scene's, or the last one submitted to it) are copied; `out_rgba_dev` (device memory,
+ *                       layout per params->out_layout) must stay valid until the frame has been waited for.  With
+ *                       frames_in_flight frames queued or running it fails with RT_ERR_BAD_ARGUMENT: wait for one first.
+ *   rt_sequence_wait    waits for the oldest frame not yet waited for and returns its status and statistics
+ *                       (RT_ERR_BAD_ARGUMENT when no frame is in flight).  Frames complete in the order submitted.
+ * Submit and wait are for one calling thread at a time. */
+typedef struct rt_sequence rt_sequence;
+int rt_sequence_create(const rt_scene_desc *desc, int device, int flags, int frames_in_flight, rt_sequence **out);
+void rt_sequence_destroy(rt_sequence *seq);
+int rt_sequence_frames_in_flight(const rt_sequence *seq);
+int rt_sequence_submit(rt_sequence *seq, const rt_render_params *params, const rt_camera *camera, void *out_rgba_dev);
+int rt_sequence_wait(rt_sequence *seq, rt_stats *stats);
+
 /* Parity/debug views of the same kernels.
  * Per-sample closest hit of the primary rays (the first getClosestIntersection
  * of rayTrace, kernel.cu:531): prim_ids[i] (-1 = miss) and t[i] for sample

@@ -5,9 +5,9 @@ raytracer_amd/csrc by __graft_entry__.build()); this package is the thin Python
 mirror of that interface.
 """
 from . import abi, tiles
-from .api import (COOK_TORRANCE, PHONG, MultiScene, RaytracerError, Scene, device_count, launch_kernel, load_bmp, make_params, parse_pov,
+from .api import (COOK_TORRANCE, PHONG, MultiScene, RaytracerError, Scene, Sequence, device_count, launch_kernel, load_bmp, make_params, parse_pov,
                   tile_count, write_tga)
 from .scene import SceneData, default_material, identity_modifier
 
-__all__ = ["abi", "tiles", "COOK_TORRANCE", "PHONG", "MultiScene", "RaytracerError", "Scene", "SceneData", "default_material",
+__all__ = ["abi", "tiles", "COOK_TORRANCE", "PHONG", "MultiScene", "RaytracerError", "Scene", "SceneData", "Sequence", "default_material",
            "device_count", "identity_modifier", "launch_kernel", "load_bmp", "make_params", "parse_pov", "tile_count", "write_tga"]

@@ -115,6 +115,7 @@ class SceneInfo(C.Structure):
 EXPORTED_SYMBOLS = [
     "rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_create_host", "rt_scene_destroy", "rt_scene_get_info",
     "rt_scene_get_bvh", "rt_scene_set_camera", "rt_render", "rt_render_device", "rt_tile_count", "rt_tiles_live",
+    "rt_sequence_create", "rt_sequence_destroy", "rt_sequence_frames_in_flight", "rt_sequence_submit", "rt_sequence_wait",
     "rt_multi_create", "rt_multi_destroy", "rt_multi_device_count", "rt_multi_set_camera", "rt_multi_render", "rt_multi_render_device",
     "rt_untile_device", "rt_trace_primary", "rt_trace_rays", "rt_trace_rays_static", "rt_render_samples",
     "rt_parse_pov", "rt_scene_desc_free", "rt_load_bmp", "rt_write_tga", "launch_kernel",
@@ -152,6 +153,12 @@ def load_library(path=None):
     lib.rt_trace_primary.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
     lib.rt_trace_rays.argtypes = [vp, i64c, vp, vp, vp, vp]
     lib.rt_trace_rays_static.argtypes = [vp, i64c, vp, vp, vp, vp]
+    lib.rt_sequence_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.rt_sequence_destroy.argtypes = [vp]
+    lib.rt_sequence_destroy.restype = None
+    lib.rt_sequence_frames_in_flight.argtypes = [vp]
+    lib.rt_sequence_submit.argtypes = [vp, C.POINTER(RenderParams), C.POINTER(Camera), vp]
+    lib.rt_sequence_wait.argtypes = [vp, C.POINTER(Stats)]
     lib.rt_multi_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(vp)]
     lib.rt_multi_destroy.argtypes = [vp]
     lib.rt_multi_destroy.restype = None

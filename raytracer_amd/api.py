@@ -189,6 +189,54 @@ class Scene:
         return rgb, st.as_dict()
 
 
+class Sequence:
+    """A sequence of frames of one scene with several frames in flight on one device (rt_sequence_*): a scene replica,
+    a stream and a host thread per frame in flight; submit() returns at once, wait() returns the oldest frame's stats."""
+
+    def __init__(self, data: SceneData, device=0, frames_in_flight=2, counters=False, fast_bvh=False):
+        self._lib = abi.load_library()
+        desc, keep = data.to_desc()
+        h = C.c_void_p()
+        flags = (abi.RT_SCENE_COUNTERS if counters else 0) | (abi.RT_SCENE_FAST_BVH if fast_bvh else 0)
+        _check(self._lib, self._lib.rt_sequence_create(C.byref(desc), device, flags, frames_in_flight, C.byref(h)))
+        self._h = h
+        del keep
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rt_sequence_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def frames_in_flight(self):
+        return self._lib.rt_sequence_frames_in_flight(self._h)
+
+    def submit(self, params, out_ptr, camera=None):
+        """Queue a frame into device memory at `out_ptr`; camera = None or a dict of pos / up / right / look_at."""
+        cam = None
+        if camera is not None:
+            cam = abi.Camera()
+            for k in ("pos", "up", "right", "look_at"):
+                getattr(cam, k)[:] = [float(x) for x in camera[k]]
+        _check(self._lib, self._lib.rt_sequence_submit(self._h, C.byref(params), C.byref(cam) if cam is not None else None, C.c_void_p(out_ptr)))
+
+    def wait(self):
+        st = abi.Stats()
+        _check(self._lib, self._lib.rt_sequence_wait(self._h, C.byref(st)))
+        return st.as_dict()
+
+
 class MultiScene:
     """One frame on several devices (rt_multi_*): a scene replica per entry of `devices`, tiles dealt round-robin,
     compact tile buffers gathered on the first device, un-tiled there.  A device may be listed more than once."""

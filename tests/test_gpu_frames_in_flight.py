@@ -64,3 +64,58 @@ def test_two_threads_two_scenes_same_bytes(name, shading, spp):
         for i in range(2):
             got = bufs[i][r].cpu().numpy().reshape(h, w, 4)
             assert got.tobytes() == want[2 * r + i].tobytes(), (r, i)
+
+
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+def test_sequence_driver_same_bytes(in_flight):
+    """rt_sequence_*: the same frames through the library's own sequence driver (a replica, stream and thread per frame
+    in flight), cameras submitted with the frames; statistics come back in submission order."""
+    sd = ra.SceneData.load(os.path.join(G, "bunny.npz"))
+    w, h, n = 400, 240, 9
+    base = {k: np.array(v, np.float32) for k, v in sd.camera.items()}
+    cams = []
+    for k in range(n):
+        c = dict(base)
+        c["pos"] = base["pos"] + np.array([0.2 * k, 0.0, 0.1 * k], np.float32)
+        cams.append(c)
+    want, want_rays = [], []
+    with ra.Scene(sd) as sc:
+        for c in cams:
+            sc.set_camera(c["pos"], c["up"], c["right"], c["look_at"])
+            f, st = sc.render(w, h, 4, abi.RT_COOK_TORRANCE, abi.RT_JITTER_HASH, 2)
+            want.append(f.copy()); want_rays.append(st["rays_total"])
+    p = ra.make_params(w, h, 4, abi.RT_COOK_TORRANCE, abi.RT_JITTER_HASH, 2)
+    bufs = [torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    got_rays = []
+    with ra.Sequence(sd, frames_in_flight=in_flight) as seq:
+        assert seq.frames_in_flight() == in_flight
+        with pytest.raises(ra.RaytracerError):
+            seq.wait()                                   # nothing in flight
+        for k in range(n):
+            if k >= in_flight:
+                got_rays.append(seq.wait()["rays_total"])
+            seq.submit(p, bufs[k].data_ptr(), cams[k])
+        while len(got_rays) < n:
+            got_rays.append(seq.wait()["rays_total"])
+    torch.cuda.synchronize()
+    assert got_rays == want_rays
+    for k in range(n):
+        assert bufs[k].cpu().numpy().reshape(h, w, 4).tobytes() == want[k].tobytes(), k
+
+
+def test_sequence_driver_refuses_more_frames_than_it_holds():
+    sd = ra.SceneData.load(os.path.join(G, "cornell.npz"))
+    p = ra.make_params(64, 48, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, 0)
+    bufs = [torch.zeros(64 * 48 * 4, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    with ra.Sequence(sd, frames_in_flight=2) as seq:
+        seq.submit(p, bufs[0].data_ptr())
+        seq.submit(p, bufs[1].data_ptr())
+        with pytest.raises(ra.RaytracerError):
+            seq.submit(p, bufs[2].data_ptr())
+        seq.wait()
+        seq.submit(p, bufs[2].data_ptr())
+        seq.wait(); seq.wait()
+    torch.cuda.synchronize()
+    assert bufs[0].cpu().numpy().tobytes() == bufs[1].cpu().numpy().tobytes() == bufs[2].cpu().numpy().tobytes()
+    with pytest.raises(ra.RaytracerError):
+        ra.Sequence(sd, frames_in_flight=0)
