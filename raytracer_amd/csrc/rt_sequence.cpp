@@ -109,6 +109,11 @@ extern "C" int rt_sequence_create(const rt_scene_desc *desc, int device, int fla
    for (Slot &s : q->slots) {
       int rc = rt_scene_create(desc, device, flags, &s.scene);
       if (rc != RT_OK) { std::string why = rt_last_error(); rt_sequence_destroy(q); rt_set_error("%s", why.c_str()); return rc; }
+   }
+   /* The streams are made one after the other, after everything else: the runtime deals its few hardware queues out to
+    * streams in the order they are created, and two replicas whose streams shared a queue would take turns instead of
+    * overlapping. */
+   for (Slot &s : q->slots) {
       if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) {
          rt_sequence_destroy(q);
          rt_set_error("rt_sequence_create: stream creation failed");
