@@ -343,6 +343,14 @@ int rt_sequence_wait(rt_sequence *seq, rt_stats *stats);
 int rt_trace_primary(const rt_scene *scene, const rt_render_params *params,
                      int32_t *prim_ids_host, float *t_host);
 
+/* The same view of the frame the scene rendered last (rt_render / rt_render_device, whole launch): the closest hits its
+ * primaries really got, as the frame's own launch stored them -- with the tile start order, the second tree and the
+ * tiles left out of the launch all as that frame had them (a sample of a tile that was left out reads prim -1,
+ * t FLT_MAX, which is what the frame took it for).  n = width*s*height*s of that frame.  Valid until the scene's next
+ * call; RT_ERR_BAD_ARGUMENT if the last call was not a frame rendered in one launch.  Like rt_trace_primary this is
+ * the first getClosestIntersection of rayTrace (kernel.cu:531) per sample. */
+int rt_frame_primary_hits(const rt_scene *scene, int32_t *prim_ids_host, float *t_host, int64_t n);
+
 /* Closest hit of arbitrary rays: rays_host = n x {ox,oy,oz,dx,dy,dz};
  * to_beat_host may be NULL (= -FLT_MAX for every ray, kernel.cu:84). */
 int rt_trace_rays(const rt_scene *scene, int64_t n, const float *rays_host,

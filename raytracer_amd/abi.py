@@ -117,7 +117,7 @@ EXPORTED_SYMBOLS = [
     "rt_scene_get_bvh", "rt_scene_set_camera", "rt_render", "rt_render_device", "rt_tile_count", "rt_tiles_live",
     "rt_sequence_create", "rt_sequence_destroy", "rt_sequence_frames_in_flight", "rt_sequence_submit", "rt_sequence_wait",
     "rt_multi_create", "rt_multi_destroy", "rt_multi_device_count", "rt_multi_set_camera", "rt_multi_render", "rt_multi_render_device",
-    "rt_untile_device", "rt_trace_primary", "rt_trace_rays", "rt_trace_rays_static", "rt_render_samples",
+    "rt_untile_device", "rt_trace_primary", "rt_frame_primary_hits", "rt_trace_rays", "rt_trace_rays_static", "rt_render_samples",
     "rt_parse_pov", "rt_scene_desc_free", "rt_load_bmp", "rt_write_tga", "launch_kernel",
 ]
 
@@ -151,6 +151,7 @@ def load_library(path=None):
     lib.rt_tiles_live.argtypes = [vp, C.POINTER(RenderParams), vp, C.c_int]
     lib.rt_untile_device.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.rt_trace_primary.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
+    lib.rt_frame_primary_hits.argtypes = [vp, vp, vp, i64c]
     lib.rt_trace_rays.argtypes = [vp, i64c, vp, vp, vp, vp]
     lib.rt_trace_rays_static.argtypes = [vp, i64c, vp, vp, vp, vp]
     lib.rt_sequence_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]

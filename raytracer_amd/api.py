@@ -167,6 +167,15 @@ class Scene:
         _check(self._lib, self._lib.rt_trace_primary(self._h, C.byref(p), prim.ctypes.data, t.ctypes.data))
         return prim, t
 
+    def frame_primary_hits(self, width, height, sample_count=1):
+        """(prim, t) of the primaries of the frame rendered last, as that frame's own launch stored them."""
+        s = int(round(sample_count ** 0.5))
+        n = width * s * height * s
+        prim = np.empty(n, np.int32)
+        t = np.empty(n, np.float32)
+        _check(self._lib, self._lib.rt_frame_primary_hits(self._h, prim.ctypes.data, t.ctypes.data, n))
+        return prim, t
+
     def trace_rays(self, rays, to_beat=None, static=False):
         """Closest hits of arbitrary rays (n x {o, d}); `static` goes through rt_trace_rays_static, the variant
         that allocates no device memory (at most abi.RT_TRACE_RAYS_STATIC_MAX rays)."""

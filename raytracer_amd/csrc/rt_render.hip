@@ -1778,6 +1778,9 @@ struct rt_scene {
    int probe_step;          /* frames of the current size rendered so far, up to the end of the try-out */
    long long probe_key[4];
    float probe_ms[4];
+   /* the one-launch frame rendered last, for rt_frame_primary_hits: where its primaries' hits lie in the arena (they
+    * stay there until the scene's next call) */
+   struct LastFrame { bool valid; DGrid g; long long np; long long hits_offset; bool culled; int n_sel; } last_frame;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -2413,6 +2416,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
    if ((long long)p->width * sroot > 0x3fffffff / (long long)(p->height * (long long)sroot)) { rt_set_error("frame too large"); return RT_ERR_TOO_LARGE; }
    HIP_TRY(hipSetDevice(s->device));
    if (view == VIEW_PRIMARY) max_rec = 1;
+   s->last_frame.valid = false;
 
    int tile_first = p->tile_first, tile_stride = p->tile_stride > 0 ? p->tile_stride : 1;
    int n_sel = rt_tile_count(p->width, p->height, tile_first, tile_stride);
@@ -2451,6 +2455,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
 
    int attempts = 0;
    bool culled_frame = false;      /* the frame left tiles out (s->tile_live says which) */
+   long long last_hits_offset = -1;   /* a one-launch frame: where its hits lie in the arena */
    for (int attempt = 0;; attempt++) {
       memset(&st, 0, sizeof st);
       attempts = attempt + 1;
@@ -2489,6 +2494,7 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
       const bool fuse = view == VIEW_FRAME && s->fuse_resolve;
       const size_t o_bounce = carve(sizeof(unsigned) * 2 * (size_t)chunk_tiles);      /* and, behind those, the same per tile for "hit anything" */
       const size_t slice = used;
+      last_hits_offset = n_chunks == 1 ? (long long)o_hits : -1;
       if (slice * (size_t)ring > s->arena.cap) { int rc = arena_reserve(s->arena, slice * (size_t)ring); if (rc != RT_OK) return rc; }
       { int rc = ensure_lists(s); if (rc != RT_OK) return rc; }
 #define AT(T, r, off) ((T *)(s->arena.base + (size_t)(r) * slice + (off)))
@@ -2760,6 +2766,11 @@ static int render_impl(const rt_scene *cs, const rt_render_params *p, int view, 
          s->filter_choice = best;
       }
    }
+   if (view == VIEW_FRAME && last_hits_offset >= 0) {
+      g.k0 = 0;
+      s->last_frame.g = g; s->last_frame.np = (long long)n_sel * per_tile; s->last_frame.hits_offset = last_hits_offset;
+      s->last_frame.culled = culled_frame; s->last_frame.n_sel = n_sel; s->last_frame.valid = true;
+   }
    st.second_tree = filter_kinds;
    st.max_ray_steps = s->h_stats[ST_MAX_RAY_STEPS * RT_STAT_REPL];
    st.max_spawn_list = s->h_stats[ST_MAX_LIST * RT_STAT_REPL];
@@ -2853,6 +2864,39 @@ extern "C" int rt_trace_primary(const rt_scene *scene, const rt_render_params *p
           hipMemcpy(t_host, d_t, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { rt_set_error("copy back failed"); rc = RT_ERR_HIP; }
    }
    (void)hipFree(d_prim); (void)hipFree(d_t);
+   return rc;
+}
+
+extern "C" int rt_frame_primary_hits(const rt_scene *scene, int32_t *prim_host, float *t_host, int64_t n)
+{
+   if (!scene || !prim_host || !t_host) { rt_set_error("rt_frame_primary_hits: null argument"); return RT_ERR_BAD_ARGUMENT; }
+   if (scene->device < 0) { rt_set_error("scene was created without a device"); return RT_ERR_NO_DEVICE; }
+   const rt_scene::LastFrame &f = scene->last_frame;
+   if (!f.valid) { rt_set_error("rt_frame_primary_hits: the scene's last call was not a frame rendered in one launch"); return RT_ERR_BAD_ARGUMENT; }
+   const DGrid &g = f.g;
+   const size_t ns = (size_t)g.res_w * (size_t)g.res_h;
+   if (n != (int64_t)ns) { rt_set_error("rt_frame_primary_hits: room for %lld samples, the frame has %zu", (long long)n, ns); return RT_ERR_BAD_ARGUMENT; }
+   HIP_TRY(hipSetDevice(scene->device));
+   int *d_prim = nullptr; float *d_t = nullptr;
+   HIP_TRY(hipMalloc((void **)&d_prim, ns * 4));
+   if (hipMalloc((void **)&d_t, ns * 4) != hipSuccess) { (void)hipFree(d_prim); rt_set_error("hipMalloc failed"); return RT_ERR_HIP; }
+   (void)hipMemset(d_prim, 0xff, ns * 4); (void)hipMemset(d_t, 0, ns * 4);
+   const Hit *hits = (const Hit *)(scene->arena.base + f.hits_offset);
+   hipLaunchKernelGGL(k_unslot_hits, dim3(grid_for(f.np)), dim3(RT_BLOCK), 0, nullptr, g, hits, f.np, scene->d.prim_ids, scene->d.n_prims, d_prim, d_t);
+   int rc = RT_OK;
+   if (hipMemcpy(prim_host, d_prim, ns * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+       hipMemcpy(t_host, d_t, ns * 4, hipMemcpyDeviceToHost) != hipSuccess) { rt_set_error("copy back failed"); rc = RT_ERR_HIP; }
+   (void)hipFree(d_prim); (void)hipFree(d_t);
+   if (rc == RT_OK && f.culled) {
+      /* a tile that was left out of the launch has no stored hits: the frame took every sample of it for a miss */
+      for (int k = 0; k < f.n_sel; k++) {
+         if (scene->tile_live[(size_t)k]) continue;
+         const long long tile = (long long)g.tile_first + (long long)k * g.tile_stride;
+         const long long x0 = (tile % g.tiles_x) * g.ts, y0 = (tile / g.tiles_x) * g.ts;
+         for (long long y = y0; y < y0 + g.ts && y < g.res_h; y++)
+            for (long long x = x0; x < x0 + g.ts && x < g.res_w; x++) { prim_host[y * g.res_w + x] = -1; t_host[y * g.res_w + x] = FLT_MAX; }
+      }
+   }
    return rc;
 }
 
