@@ -87,6 +87,11 @@ typedef struct rt_flat_scene {
    size_t n_texels;
    int32_t any_xform;
    int32_t bounds_in_range;    /* every node bound is finite with magnitude <= 2^40 (or zero) */
+   /* Sphere::intersects (Sphere.h:42-66) takes the difference of two products of the size (distance to the sphere)^2:
+    * what it reports as the hit lies off the sphere by up to about 2^-22 * distance^2 / radius (more for a sphere
+    * squeezed by its transform).  The largest of 1 / radius over the scene's spheres, in world units, with that
+    * squeeze folded in; 0 for a scene without spheres.  See RayCtx::wide. */
+   float sphere_coeff;
 } rt_flat_scene;
 
 #ifdef __cplusplus

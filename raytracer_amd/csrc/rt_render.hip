@@ -64,6 +64,10 @@ struct DScene {
    int filter_kinds; /* which rays of this launch start in the second tree: bit 0 closest-hit rays, bit 1 shadow feelers */
    int fast_ok;      /* every BVH bound is finite and below 2^40 in magnitude */
    int any_xform;    /* some BVH primitive carries a transform */
+   /* for the margins a ray gives the second tree (make_ray_ctx): the middle of the box that holds the scene's spheres,
+    * half its diagonal, and rt_flat_scene::sphere_coeff */
+   float mid_x, mid_y, mid_z, mid_rad, sphere_coeff;
+   float origin_coeff;   /* RayCtx::wide as a fraction of the origin's largest coordinate (2^-20) */
 };
 
 /* Division of a 32-bit unsigned by a divisor fixed for the launch, without the 30-odd instructions of the general
@@ -281,6 +285,39 @@ __device__ __forceinline__ bool tie_prefers_new(const rt_dev_prim *prims, const 
 /* ======================================================================= */
 /* traversal: getClosestIntersection, kernel.cu:83-200                      */
 /* ======================================================================= */
+/* The per-ray constants of the box test, with the margins this ray gives the second tree.
+ *
+ * The reference's walk tests a primitive only after the ray has passed the box test of that primitive's own leaf box,
+ * and the second tree's leaf box for the primitive contains that box; so the second tree reaches every primitive the
+ * reference could test as long as its box test never turns away a box the reference's would let the ray into.  The
+ * two tests round differently (their boxes differ), by a few units in the last place of the differences they take
+ * from the ray's origin -- 1e-4 per subtraction for a light a thousand units from a scene of size one.  Beside the
+ * widening its boxes carry for the size of their own coordinates, the second tree's boxes are therefore widened, for
+ * this ray, by 2^-20 of the origin's largest coordinate (RayCtx::wide; eight times the box test's rounding).
+ *
+ * What remains is where along the ray a primitive reports its hit.  The second tree does not enter boxes that start
+ * behind the stretch a ray cares about, on the grounds that a primitive is met no earlier than its box.  Triangles
+ * and boxes keep to that within the margins used there (RT_LOOK_*, RT_FEELER_REL).  Sphere::intersects (Sphere.h:42-66)
+ * does not: it takes the difference of two products of the size (distance)^2 and reports its hit off the sphere by
+ * up to about 2^-22 distance^2 / radius (measured: 2^-22.6 at worst in 40 000 rays of balls2 from one, ten and a
+ * hundred times its lights' distances).  `slack` is that, for this ray, as a parameter along it; it is added where
+ * the second tree cuts a feeler's stretch short, it rides on RT_LOOK_ABS for the other rays, and a ray for which it
+ * exceeds RT_SLACK_MAX does not use the second tree at all. */
+__device__ __forceinline__ RayCtx make_ray_ctx(const DScene &sc, const Ray &r, float &slack)
+{
+   RayCtx c = make_ctx(r);
+   c.wide = sc.origin_coeff * fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
+   slack = 0.0f;
+   if (sc.sphere_coeff > 0.0f) {
+      const F3 e = r.o - mk3(sc.mid_x, sc.mid_y, sc.mid_z);
+      const float far = sqrtf(dot3(e, e)) + sc.mid_rad;
+      slack = (2.384185791015625e-7f * sc.sphere_coeff) * (far * far) / sqrtf(dot3(r.d, r.d));
+      if (!(slack <= RT_SLACK_MAX)) c.par |= RT_PAR_NO_FILTER;
+   }
+   if (!sc.fast_ok) c.fast = false;
+   return c;
+}
+
 struct StackEntry { int child; float dist; };
 extern __shared__ StackEntry lds_stack[];
 
@@ -604,7 +641,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
    bool wave_lit = false;              /* wave-uniform: some lane holds a ray the short box test is not valid for */
    bool burst_filter = false;          /* wave-uniform: some lane of the current burst of node steps is in the second tree */
    RayCtx c;
-   c.r.o = mk3(0, 0, 0); c.r.d = mk3(1, 1, 1); c.yx = c.yy = c.yz = 1.0f; c.par = 0; c.fast = true;
+   c.r.o = mk3(0, 0, 0); c.r.d = mk3(1, 1, 1); c.yx = c.yy = c.yz = 1.0f; c.par = 0; c.fast = true; c.wide = 0.0f;
    float t = FLT_MAX, toBeat = -FLT_MAX;
    int closest = -1, cur = RT_CUR_IDLE, sp = 0, tag = 0;   /* cur: node index, ~primitive, or RT_CUR_IDLE while the lane has no ray */
    int mode = MODE_EXTEND;             /* OUT_CHAIN: what this lane's ray is; tag: depth level + 1 (closest-hit rays) or the light (feelers) */
@@ -764,8 +801,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
          left = slab_literal(c.r, na.x, na.y, na.z, na.w, nb.x, nb.y);
          right = slab_literal(c.r, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w);
       } else {
-         SlabAB sl = slab_ab<VARIANT == 1>(c, na.x, na.y, na.z, na.w, nb.x, nb.y);
-         SlabAB sr = slab_ab<VARIANT == 1>(c, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w);
+         /* in the second tree the boxes are wider by the ray's own margin (RayCtx::wide); in the reference's, as they are */
+         const float w = (TWO && (mode & MODE_FILTER)) ? c.wide : 0.0f;
+         const F3 up = mk3(c.r.o.x + w, c.r.o.y + w, c.r.o.z + w), dn = mk3(c.r.o.x - w, c.r.o.y - w, c.r.o.z - w);
+         SlabAB sl = slab_ab<VARIANT == 1>(c, up, dn, na.x, na.y, na.z, na.w, nb.x, nb.y);
+         SlabAB sr = slab_ab<VARIANT == 1>(c, up, dn, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w);
          left = slab_value(sl); right = slab_value(sr);
          if (TWO && burst_filter) {
             /* a ray still in the miss filter's tree asks the filter's question of the same two numbers */
@@ -824,13 +864,13 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
     *  - A feeler that meets a primitive in front of its target leaves the second tree and makes the reference's walk
     *    from its root, unchanged.
     * Rays outside the short box test's range do not use the second tree. */
-   auto enter_tree = [&]() {
+   auto enter_tree = [&](float slack) {
       const int kind_bit = (mode & MODE_KIND) == MODE_EXTEND ? 1 : 2;
-      if (TWO && (sc.filter_kinds & kind_bit) && c.fast && !wave_lit) {
+      if (TWO && (sc.filter_kinds & kind_bit) && c.fast && !wave_lit && !(c.par & RT_PAR_NO_FILTER)) {
          cur = sc.filter_root; mode |= MODE_FILTER;
          if (OUT == OUT_CHAIN) {
             if ((mode & MODE_KIND) == MODE_EXTEND) toBeat = FLT_MAX;      /* the nearest of the other primitives, so far */
-            else t = toBeat * (1.0f + RT_FEELER_REL);                     /* nothing that starts behind the target can shadow it */
+            else t = toBeat * (1.0f + RT_FEELER_REL) + slack;             /* nothing that starts behind the target can shadow it */
          }
       } else cur = sc.root;
    };
@@ -956,10 +996,10 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
          Ray r;
          r.o = cont_refl ? mk3(b.ro[0], b.ro[1], b.ro[2]) : mk3(b.to[0], b.to[1], b.to[2]);
          r.d = cont_refl ? mk3(b.rd[0], b.rd[1], b.rd[2]) : mk3(b.td[0], b.td[1], b.td[2]);
-         c = make_ctx(r);
-         if (!sc.fast_ok) c.fast = false;
+         float slack;
+         c = make_ray_ctx(sc, r, slack);
          toBeat = -FLT_MAX; idx = (unsigned)(cont_refl ? out.child_refl : out.child_refr); tag = tag + 1; mode = MODE_EXTEND;
-         t = FLT_MAX; closest = -1; sp = 0; enter_tree();
+         t = FLT_MAX; closest = -1; sp = 0; enter_tree(slack);
          active = true; ray_steps = 0; born = 0; RT_DBG_RAY_START;
          if (cur == RT_ROOT_EMPTY) finish(false);
       }
@@ -1061,8 +1101,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
                   const unsigned fw = __hip_atomic_load(a.flag_words + (size_t)node * a.flag_stride + (k >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   unneeded = ((fw >> (k & 31u)) & 1u) != 0u;
                }
-               c = make_ctx(feeler);
-               if (!sc.fast_ok) c.fast = false;
+               float slack;
+               c = make_ray_ctx(sc, feeler, slack);
                tag = (int)k; idx = node;
                t = FLT_MAX; closest = -1; sp = 0; ray_steps = 0; born = 0; RT_DBG_RAY_START;
                if (hprim >= sc.n_prims) {
@@ -1071,11 +1111,12 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
                   if (param == -1.0f) n_skipped++;          /* lit, whatever the walk would find: its bit stays clear */
                   else if (unneeded) n_unneeded++;          /* nobody looks at its bit */
                   else {
-                     toBeat = param; mode = MODE_SHADOW; enter_tree(); active = true;
+                     toBeat = param; mode = MODE_SHADOW; enter_tree(slack); active = true;
                      if (cur == RT_ROOT_EMPTY) finish(false);
                   }
                } else {
-                  mode = unneeded ? (MODE_SETUP | MODE_UNNEEDED) : MODE_SETUP; cur = ~hprim; toBeat = -FLT_MAX; active = true;
+                  /* (until its own-surface test is done the feeler keeps its slack where its t will be) */
+                  mode = unneeded ? (MODE_SETUP | MODE_UNNEEDED) : MODE_SETUP; cur = ~hprim; toBeat = -FLT_MAX; t = slack; active = true;
                }
             } else {
                bool have = false;
@@ -1117,10 +1158,10 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
 #endif
                   if (q.valid) {
                      Ray r; r.o = mk3(q.ox, q.oy, q.oz); r.d = mk3(q.dx, q.dy, q.dz);
-                     c = make_ctx(r);
-                     if (!sc.fast_ok) c.fast = false;
+                     float slack;
+                     c = make_ray_ctx(sc, r, slack);
                      toBeat = q.to_beat; idx = (unsigned)my; tag = q.valid; mode = MODE_EXTEND;
-                     t = FLT_MAX; closest = -1; sp = 0; enter_tree();
+                     t = FLT_MAX; closest = -1; sp = 0; enter_tree(slack);
                      active = true; ray_steps = 0; born = 0; RT_DBG_RAY_START;
                      if (cur == RT_ROOT_EMPTY) finish(false);
                   }
@@ -1136,7 +1177,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
             }
          }
          m_active = __ballot(active);
-         wave_par = __ballot(active && c.par != 0) != 0;
+         wave_par = __ballot(active && (c.par & RT_PAR_AXES) != 0) != 0;
          wave_lit = __ballot(active && !c.fast) != 0;
          /* the literal box test has no reading for the second tree's question: a wave that has to use it keeps no ray there */
          if (TWO && wave_lit && active && (mode & MODE_FILTER)) leave_filter();
@@ -1235,7 +1276,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
                if (dist == -1.0f) { n_skipped++; active = false; cur = RT_CUR_IDLE; }
                else if (mode & MODE_UNNEEDED) { n_unneeded++; active = false; cur = RT_CUR_IDLE; }      /* its bit stays clear; nobody looks at it */
                else {
-                  toBeat = dist; mode = MODE_SHADOW; enter_tree();
+                  const float slack = t;
+                  toBeat = dist; mode = MODE_SHADOW; t = FLT_MAX; enter_tree(slack);
                   if (cur == RT_ROOT_EMPTY) finish(false);
                }
             } else {
@@ -1993,12 +2035,33 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
       if (s->filter_auto && h.n_prims > 0 && glass * 4 > (long long)h.n_prims) s->filter_choice = 0;
    }
    s->d.any_xform = h.any_xform;
+   s->d.sphere_coeff = h.sphere_coeff; s->d.origin_coeff = 9.5367431640625e-7f;
+   /* (for measurements: what the two margins cost) */
+   if (const char *e = getenv("RT_SPHERE_MARGIN")) s->d.sphere_coeff *= (float)atof(e);
+   if (const char *e = getenv("RT_ORIGIN_MARGIN")) s->d.origin_coeff *= (float)atof(e);
    /* a bounce ray needs a material with reflection or refraction above 0 (kernel.cu:360-374) */
    s->can_bounce = false;
    for (int k = 0; k < h.n_materials; k++) if (h.materials[k].refl > 0.0f || h.materials[k].refr > 0.0f) s->can_bounce = true;
    s->lights_finite = true;
    for (int k = 0; k < h.n_lights; k++) for (int j = 0; j < 3; j++) if (!std::isfinite(h.lights[k].clr[j])) s->lights_finite = false;
    scene_bounds(s);
+   if (h.sphere_coeff > 0.0f) {
+      /* the box that holds the spheres (other primitives do not count: a floor of two large triangles would put every
+       * ray far from "the scene") */
+      double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, r2 = 0.0;
+      bool ok = s->bounds_ok && h.prim_boxes != nullptr;
+      for (int k = 0; k < h.n_prims && ok; k++) {
+         if (h.prims[k].type != RT_PRIM_SPHERE) continue;
+         for (int j = 0; j < 3; j++) {
+            lo[j] = std::min(lo[j], (double)h.prim_boxes[6 * (size_t)k + j]); hi[j] = std::max(hi[j], (double)h.prim_boxes[6 * (size_t)k + 3 + j]);
+         }
+      }
+      for (int j = 0; j < 3 && ok; j++) { ok = lo[j] <= hi[j]; const double half = 0.5 * (hi[j] - lo[j]); r2 += half * half; }
+      if (ok) {
+         s->d.mid_x = (float)(0.5 * (lo[0] + hi[0])); s->d.mid_y = (float)(0.5 * (lo[1] + hi[1])); s->d.mid_z = (float)(0.5 * (lo[2] + hi[2]));
+         s->d.mid_rad = (float)std::sqrt(r2);
+      } else s->d.filter_root = RT_ROOT_EMPTY;      /* no usable bounds to measure a ray's distance from the spheres by: such a scene goes without the second tree */
+   }
 
    if (hipMalloc((void **)&s->d_ctr, RT_CTR_WORDS * sizeof(unsigned long long)) != hipSuccess ||
        hipMalloc((void **)&s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long)) != hipSuccess ||

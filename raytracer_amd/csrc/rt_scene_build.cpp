@@ -596,6 +596,24 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
    out->n_nodes = (int32_t)flat.size(); out->n_materials = (int32_t)b.materials.size();
    out->root = root; out->tree_depth = depth; out->any_xform = b.any_xform;
    out->bounds_in_range = 1;
+   {
+      /* per sphere: the smallest half-axis it has in the world is at least radius * sqrt(3) / |inv_trans| (Frobenius norm
+       * of the 3x3 part, which bounds the largest stretch of inv_trans), and |trans| |inv_trans| / 3 says how unevenly the
+       * transform stretches (1 for rotations and uniform scalings) */
+      double coeff = 0.0;
+      for (int i = 0; i < d->n_spheres; i++) {
+         const rt_sphere &sp = d->spheres[i];
+         double nt = 0.0, ni = 0.0;
+         for (int c = 0; c < 3; c++)
+            for (int r = 0; r < 3; r++) { nt += (double)sp.mod.trans[c * 4 + r] * sp.mod.trans[c * 4 + r]; ni += (double)sp.mod.inv_trans[c * 4 + r] * sp.mod.inv_trans[c * 4 + r]; }
+         nt = std::sqrt(nt); ni = std::sqrt(ni);
+         double cond = nt * ni / 3.0; if (!(cond >= 1.0)) cond = 1.0;
+         const double rmin = std::fabs((double)sp.r) * std::sqrt(3.0) / ni;
+         const double k = cond * cond / rmin;
+         if (!(k <= 3.0e38)) coeff = 3.0e38; else if (k > coeff) coeff = k;
+      }
+      out->sphere_coeff = (float)coeff;
+   }
    for (size_t k = 0; k < flat.size(); k++) {
       const float *v = flat[k].lmin;   /* lmin, lmax, rmin, rmax are 12 consecutive floats */
       for (int j = 0; j < 12; j++)

@@ -169,3 +169,31 @@ def random_scene(seed, n_spheres=12, n_triangles=10, n_boxes=5, n_smooth=6, n_pl
     sd.camera = {"pos": np.array([0, 1, 7], np.float32), "up": np.array([0, 1, 0], np.float32),
                  "right": np.array([1.3333, 0, 0], np.float32), "look_at": np.array([0, 0, 0], np.float32)}
     return sd
+
+
+def similar(scene: SceneData, scale=1.0, shift=(0.0, 0.0, 0.0), move_camera=True, move_lights=True):
+    """The scene under the similarity x -> scale * x + shift: composed onto every object's modifier (trans and inv_trans,
+    worked out in double and rounded once each), and applied to the lights and the camera (its up / right vectors scale, so
+    the picture is the same one) unless told to leave those where they are.  For parity runs far from the origin of the
+    coordinates and at other sizes."""
+    import copy
+    out = copy.deepcopy(scene)
+    shift = np.asarray(shift, np.float64)
+    S = np.eye(4); S[:3, :3] *= scale; S[:3, 3] = shift
+    Sinv = np.eye(4); Sinv[:3, :3] /= scale; Sinv[:3, 3] = -shift / scale
+    for name in ("spheres", "triangles", "boxes", "smooth_triangles", "planes"):
+        arr = getattr(out, name)
+        for k in range(len(arr)):
+            m = arr["mod"]["trans"][k].reshape(4, 4).T.astype(np.float64)          # stored column-major
+            mi = arr["mod"]["inv_trans"][k].reshape(4, 4).T.astype(np.float64)
+            arr["mod"]["trans"][k] = (S @ m).astype(np.float32).T.reshape(16)
+            arr["mod"]["inv_trans"][k] = (mi @ Sinv).astype(np.float32).T.reshape(16)
+    if move_lights and len(out.lights):
+        out.lights["pos"] = (out.lights["pos"].astype(np.float64) * scale + shift).astype(np.float32)
+    if move_camera and out.camera is not None:
+        cam = out.camera
+        out.camera = {"pos": (np.asarray(cam["pos"], np.float64) * scale + shift).astype(np.float32),
+                      "look_at": (np.asarray(cam["look_at"], np.float64) * scale + shift).astype(np.float32),
+                      "up": (np.asarray(cam["up"], np.float64) * scale).astype(np.float32),
+                      "right": (np.asarray(cam["right"], np.float64) * scale).astype(np.float32)}
+    return out

@@ -159,6 +159,18 @@ def test_feelers_from_a_distant_light_are_never_certified():
     assert st["shadows_certified"] == 0 and st["rays_shadow"] > 0
 
 
+@pytest.mark.parametrize("seed,scale", [(77, 20.0), (78, 60.0), (79, 200.0), (80, 60.0), (81, 60.0), (81, 1000.0)])
+def test_lights_far_from_small_spheres(seed, scale):
+    """Lights 100 to 20 000 units from a scene of unit-sized spheres, boxes and triangles.  Sphere::intersects
+    (Sphere.h:42-66) subtracts two products of the size (distance)^2, so from that far it reports its hits off the sphere by
+    a good part of the radius, in front of the sphere's own box as often as not; the reference's walk takes them as they
+    come, and a feeler's walk of the second tree has to look that much further than its target.  (With the margin of a
+    nearby light, 1 to 30 of 480 000 samples came out lit where the reference has them shadowed.)"""
+    sd = synth.random_scene(seed, n_spheres=150, n_triangles=150, n_boxes=40, n_smooth=60, n_planes=0, n_lights=2)
+    sd.lights["pos"] = sd.lights["pos"] * scale
+    both_ways(sd, 400, 300, 4, oracle=scale < 100)
+
+
 def test_feelers_certified_in_crowded_scenes_and_on_the_flake():
     sd = synth.random_scene(321, n_spheres=150, n_triangles=150, n_boxes=40, n_smooth=60, n_planes=1, n_lights=3)
     st = both_ways(sd, 200, 150, 4)
