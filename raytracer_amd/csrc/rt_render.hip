@@ -68,6 +68,8 @@ struct DScene {
     * half its diagonal, and rt_flat_scene::sphere_coeff */
    float mid_x, mid_y, mid_z, mid_rad, sphere_coeff;
    float origin_coeff;   /* RayCtx::wide as a fraction of the origin's largest coordinate (2^-20) */
+   int verify_jump;      /* every box of the reference's tree lies inside its parent's (checked when the scene is made): a ray
+                          * on its way down to one leaf may go from the root straight to the leaf's parent, see the node step */
 };
 
 /* Division of a 32-bit unsigned by a divisor fixed for the launch, without the 30-odd instructions of the general
@@ -837,8 +839,23 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
             const int hangs_at = __float_as_int(feeler ? t : toBeat);
             const float limit = feeler ? toBeat : t + RT_EQ_EPS;
             const bool right_turn = ch.y >= 0 ? hangs_at >= ch.y : ~ch.y == closest;
-            if ((right_turn ? r : l) < limit) cur = right_turn ? ch.y : ch.x;      /* at the leaf: the leaf step ends the ray */
-            else {
+            if ((right_turn ? r : l) < limit) {
+               int next = right_turn ? ch.y : ch.x;      /* at the leaf: the leaf step ends the ray */
+               /* From the root straight to the leaf's parent, for a ray that does not start inside the box it turns into
+                * here.  Every box further down the path lies inside this one, coordinate by coordinate, and the box test
+                * is a chain of correctly rounded operations, each monotone in the bound it takes: so the ray starts
+                * inside none of them (GeometryUtil.h:41-45 compares the same coordinates), their values are where the ray
+                * enters them, and those are no smaller than this box's (which is ahead: it has just been found so) and no
+                * larger than the leaf's own box's -- which the leaf's parent, one step from now, compares with the same
+                * limit.  If that one passes, every box in between would have passed. */
+               if (sc.verify_jump && cur == sc.root && next >= 0 && next != hangs_at) {
+                  const float bx0 = right_turn ? nb.z : na.x, by0 = right_turn ? nb.w : na.y, bz0 = right_turn ? nc.x : na.z;
+                  const float bx1 = right_turn ? nc.y : na.w, by1 = right_turn ? nc.z : nb.x, bz1 = right_turn ? nc.w : nb.y;
+                  const bool inside = c.r.o.x > bx0 && c.r.o.x < bx1 && c.r.o.y > by0 && c.r.o.y < by1 && c.r.o.z > bz0 && c.r.o.z < bz1;
+                  if (!inside) next = hangs_at;
+               }
+               cur = next;
+            } else {
                if (COUNT) { if (feeler) { n_shadow_cert--; } else { n_cert--; n_unreached++; } }
                mode &= MODE_KIND; t = FLT_MAX; closest = -1; cur = sc.root; sp = 0;
                if (!feeler) toBeat = -FLT_MAX;
@@ -2035,6 +2052,25 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
       if (s->filter_auto && h.n_prims > 0 && glass * 4 > (long long)h.n_prims) s->filter_choice = 0;
    }
    s->d.any_xform = h.any_xform;
+   {
+      /* every box of the reference's tree inside its parent's?  (formBVH makes them so: combineBoundingBox,
+       * BoundingBox.h:48-52, takes the smaller and the larger bound and pads; a scene with a NaN bound fails here) */
+      bool nested = n_tree > 0 && n_filter > 0;
+      for (size_t k = 0; k < n_tree && nested; k++) {
+         const rt_bvh_node &n = d_nodes[k];
+         const int32_t child[2] = {n.left, n.right};
+         const float *box[2] = {n.lmin, n.rmin};       /* lmin, lmax / rmin, rmax: six consecutive floats each */
+         for (int c = 0; c < 2 && nested; c++) {
+            if (child[c] < 0) continue;
+            const rt_bvh_node &m = d_nodes[(size_t)child[c]];
+            const float *sub[2] = {m.lmin, m.rmin};
+            for (int b = 0; b < 2; b++)
+               for (int j = 0; j < 3; j++)
+                  if (!(sub[b][j] >= box[c][j]) || !(sub[b][3 + j] <= box[c][3 + j])) nested = false;
+         }
+      }
+      s->d.verify_jump = nested && env_int("RT_VERIFY_JUMP", 1, true) ? 1 : 0;
+   }
    s->d.sphere_coeff = h.sphere_coeff; s->d.origin_coeff = 9.5367431640625e-7f;
    /* (for measurements: what the two margins cost) */
    if (const char *e = getenv("RT_SPHERE_MARGIN")) s->d.sphere_coeff *= (float)atof(e);
