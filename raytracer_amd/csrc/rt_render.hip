@@ -583,17 +583,29 @@ __device__ __forceinline__ BounceRays bounce_rays(const rt_dev_prim *prims, cons
    return b;
 }
 
+struct TraceKernArgs { DScene sc; TraceArgs a; };
+
 /* TWO: the launch uses the scene's second tree (sc.filter_root is one); without it none of the code that proves answers
  * from that tree is there */
 template <int OUT, bool COUNT, bool SPILL, bool TWO>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_SIMD, RT_WAVES_PER_SIMD))) void k_trace(DScene sc, TraceArgs a)
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_SIMD, RT_WAVES_PER_SIMD))) void k_trace(TraceKernArgs ka)
 {
+   /* The scene's arrays are used in every step and stay in scalar registers.  The launch's other arguments are mostly
+    * wanted once per refill, spawn or finished ray: each use reads its field from the kernel-argument segment afresh
+    * (a scalar load, served by the constant cache), so that a hundred values do not sit in scalar registers -- and,
+    * spilled from there, in vector registers -- for the whole launch. */
+   const DScene &sc = ka.sc;
+   auto A = [&]() {
+      unsigned zero = 0;
+      asm volatile("" : "+s"(zero));      /* (keeps the compiler from hoisting these loads to the top and holding the values) */
+      return (const TraceArgs *)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TraceKernArgs, a) + zero);
+   };
    /* The per-lane stack of deferred siblings: one column per lane in LDS.  A tree deeper than RT_LDS_STACK levels
     * (SPILL) keeps the entries beyond that in global memory, a column per lane of the launch, so that deep trees do
     * not cost the four workgroups per CU their LDS; a ray rarely defers that many siblings at once. */
    StackEntry *stack = lds_stack + threadIdx.x;
    const int stride = RT_BLOCK;
-   StackEntry *const spill = SPILL ? a.spill + ((size_t)blockIdx.x * RT_BLOCK + threadIdx.x) : nullptr;
+   StackEntry *const spill = SPILL ? A()->spill + ((size_t)blockIdx.x * RT_BLOCK + threadIdx.x) : nullptr;
    const size_t spill_stride = SPILL ? (size_t)gridDim.x * RT_BLOCK : 0;
    /* (the empty asm statements keep the two loads apart: merged into one load through a generic pointer they cost more,
     * and the compiler's check of which address space that pointer is in does not assemble for gfx950) */
@@ -609,11 +621,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
    };
    const unsigned lane = __lane_id();
    const unsigned long long below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
-   /* OUT_CHAIN: this wave's list of spawned rays and shadow items still to be started, a ring of a.list_cap entries in
+   /* OUT_CHAIN: this wave's list of spawned rays and shadow items still to be started, a ring of A()->list_cap entries in
     * global memory: entries head .. head+count-1 (wave-uniform).  Written with plain stores, read back past the
     * CU's vector cache (the reader is another lane of the same wave, some refills later). */
-   uint2 *const list = a.lists ? a.lists + (size_t)(blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * a.list_cap : nullptr;
-   const int list_mask = (int)a.list_cap - 1;
+   uint2 *const list = A()->lists ? A()->lists + (size_t)(blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * A()->list_cap : nullptr;
+   const int list_mask = (int)A()->list_cap - 1;
    int list_peak = 0;
    int list_count = 0, list_head = 0;
    auto list_put = [&](int k, uint2 v) { *reinterpret_cast<unsigned long long *>(list + ((list_head + k) & list_mask)) = (unsigned long long)v.x | ((unsigned long long)v.y << 32); };
@@ -621,8 +633,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
       unsigned long long w = __hip_atomic_load(reinterpret_cast<unsigned long long *>(list + ((list_head + k) & list_mask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return make_uint2((unsigned)w, (unsigned)(w >> 32));
    };
-   const unsigned long long n = a.n_fetch;       /* slots that are handed out */
-   unsigned long long *const stats = a.stats;
+   const unsigned long long n = A()->n_fetch;       /* slots that are handed out */
+   unsigned long long *const stats = A()->stats;
+   /* (what every turn of the loop or every finished ray wants stays in registers) */
+   const int refill_idle = A()->refill_idle, node_burst = A()->node_burst, leaf_trigger = A()->leaf_trigger;
+   Hit *const hits = A()->hits;
    const unsigned long long clock_start = COUNT ? wall_clock64() : 0ULL;     /* 100 MHz */
 #ifdef RT_DEBUG_EXIT_HIST
    const unsigned long long dbg_start = wall_clock64();
@@ -722,26 +737,26 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
 #endif
       if (OUT == OUT_CHAIN && (mode & MODE_KIND) != MODE_EXTEND) {
          /* kernel.cu:206; a feeler that is not shadowed leaves its bit as the launch found it: clear */
-         if (less_than(t, toBeat)) atomicOr(a.flag_words + (size_t)idx * a.flag_stride + ((unsigned)tag >> 5), 1u << ((unsigned)tag & 31u));
+         if (less_than(t, toBeat)) atomicOr(A()->flag_words + (size_t)idx * A()->flag_stride + ((unsigned)tag >> 5), 1u << ((unsigned)tag & 31u));
          /* A feeler that took long (the reference's walk, for one the second tree could not answer) belongs to a tile
           * that should start early next frame: the tile's cost is at least this feeler's.  (Only the feelers of
           * primaries say which tile they belong to; they are few.) */
-         if (a.tile_cost && born > RT_LONG_FEELER && idx < (unsigned)a.n) atomicMax(a.tile_cost + 2 * fd_div(idx, a.g.per_tile_div), born);
+         if (A()->tile_cost && born > RT_LONG_FEELER && idx < (unsigned)A()->n) atomicMax(A()->tile_cost + 2 * fd_div(idx, A()->g.per_tile_div), born);
       } else {
-         Hit h; h.prim = closest; h.t = t; a.hits[idx] = h;
+         Hit h; h.prim = closest; h.t = t; hits[idx] = h;
          if (OUT == OUT_CHAIN) {
             if (closest >= 0) {
-               if (a.dur) a.dur[idx] = born;
+               if (A()->dur) A()->dur[idx] = born;
                pend = true;
                if (tag == 1) {
-                  store_qray(a.rays, idx, c.r.o, c.r.d, -FLT_MAX, 1);      /* a primary: made on fetch, not stored then (bounce rays are, when they are spawned) */
-                  if (a.tile_hit) a.tile_hit[fd_div(idx, a.g.per_tile_div)] = 1u;
+                  store_qray(A()->rays, idx, c.r.o, c.r.d, -FLT_MAX, 1);      /* a primary: made on fetch, not stored then (bounce rays are, when they are spawned) */
+                  if (A()->tile_hit) A()->tile_hit[fd_div(idx, A()->g.per_tile_div)] = 1u;
                }
             } else if (tag != 1) {
                /* a bounce ray that hit nothing: nothing to spawn.  (Of a primary that hit nothing only the hit is stored:
                 * the kernels behind this one look at it first and want nothing else.) */
-               if (a.dur) a.dur[idx] = born;
-               *reinterpret_cast<float4 *>(a.recs + idx) = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));
+               if (A()->dur) A()->dur[idx] = born;
+               *reinterpret_cast<float4 *>(A()->recs + idx) = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));
             }
          }
       }
@@ -913,7 +928,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
          float m_refl = m.refl, m_refr = m.refr, m_ior = m.ior;
          out.refl = m_refl; out.alpha = m.alpha;
          m_dif = m.dif; m_spec = m.spec; m_rough = m.rough;
-         if (tag < a.max_rec && (m_refl > 0.0f || m_refr > 0.0f)) {          /* tag = level + 1 */
+         if (tag < A()->max_rec && (m_refl > 0.0f || m_refr > 0.0f)) {          /* tag = level + 1 */
             b = bounce_rays(sc.prims, sc.xforms, sc.shades, sc.planes, sc.n_prims, c.r.o.x, c.r.o.y, c.r.o.z,
                             c.r.d.x, c.r.d.y, c.r.d.z, closest, t, m_refl, m_refr, m_ior);
             want_refl = b.want_refl != 0; want_refr = b.want_refr != 0;
@@ -924,7 +939,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
       unsigned long long mR = __ballot(want_refl), mT = __ballot(want_refr), mS = __ballot(want_sh);
       unsigned cR = __popcll(mR), cT = __popcll(mT), cS = __popcll(mS);
       if (cR + cT + cS) {
-         const bool room = list != nullptr && list_count + (int)(cR + cT + cS) <= (int)a.list_cap;
+         const bool room = list != nullptr && list_count + (int)(cR + cT + cS) <= (int)A()->list_cap;
          if (!room) {
             /* The list is full: nothing of this stage is started (no queue entry is taken, the nodes keep "no child"),
              * the frame is flagged and the host renders it again with longer lists. */
@@ -933,12 +948,12 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
             if (want_sh) {
                /* the shaded point (kernel.cu:340) and its primitive, once, for the feelers of all its lights */
                F3 P = ray_point(c.r, t);
-               a.points[idx] = make_float4(P.x, P.y, P.z, __int_as_float(closest));
+               A()->points[idx] = make_float4(P.x, P.y, P.z, __int_as_float(closest));
                /* ... and its shadow bits start clear (only entries that are shaded have bits anyone reads, so they are
                 * cleared here rather than all at once before the launch; the feelers that set them start in later
                 * refills, behind the fence of a refill that takes list entries) */
-               if (!a.skip_unlit) {
-                  for (unsigned w = 0; w < a.flag_stride; w++) a.flag_words[(size_t)idx * a.flag_stride + w] = 0u;
+               if (!A()->skip_unlit) {
+                  for (unsigned w = 0; w < A()->flag_stride; w++) A()->flag_words[(size_t)idx * A()->flag_stride + w] = 0u;
                } else {
                   /* ... except those of the lights whose feeler cannot matter, with the expressions of PhongShader.h:12-22 on
                    * the values the light sums will use (same ray, same t: same floats) */
@@ -956,19 +971,19 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
                      const bool no_diffuse = (m_dif * d1) == 0.0f;
                      const bool no_specular = m_rough > 0.0f && (m_spec == 0.0f ? sp1 == sp1 : sp1 == 0.0f);
                      if (no_diffuse && no_specular) word |= 1u << (l & 31);
-                     if ((l & 31) == 31 || l + 1 == sc.n_lights) { a.flag_words[(size_t)idx * a.flag_stride + ((unsigned)l >> 5)] = word; word = 0u; }
+                     if ((l & 31) == 31 || l + 1 == sc.n_lights) { A()->flag_words[(size_t)idx * A()->flag_stride + ((unsigned)l >> 5)] = word; word = 0u; }
                   }
                }
             }
             const unsigned cnt = cR + cT;
             if (cnt > res_hi - res_lo && !res_full) {
                /* a new range of queue entries; what is left of the old one is never used and reads as a miss */
-               for (unsigned u = res_lo + lane; u < res_hi; u += 64) { Hit h; h.prim = -1; h.t = FLT_MAX; a.hits[u] = h; }
+               for (unsigned u = res_lo + lane; u < res_hi; u += 64) { Hit h; h.prim = -1; h.t = FLT_MAX; hits[u] = h; }
                unsigned base = 0;
-               if (lane == 0) base = atomicAdd(a.tail, a.reserve);
+               if (lane == 0) base = atomicAdd(A()->tail, A()->reserve);
                base = __shfl(base, 0);
-               if (base >= a.cap) { res_lo = res_hi = 0; res_full = true; }
-               else { res_lo = base; res_hi = a.cap - base < a.reserve ? a.cap : base + a.reserve; }
+               if (base >= A()->cap) { res_lo = res_hi = 0; res_full = true; }
+               else { res_lo = base; res_hi = A()->cap - base < A()->reserve ? A()->cap : base + A()->reserve; }
             }
             unsigned slotR = res_lo + __popcll(mR & below), slotT = res_lo + cR + __popcll(mT & below);
             bool okR = want_refl && slotR < res_hi, okT = want_refr && slotT < res_hi;
@@ -976,11 +991,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
             unsigned nR = __popcll(oR), nT = __popcll(oT);
             res_lo += cnt < res_hi - res_lo ? cnt : res_hi - res_lo;
             if (okT) {
-               store_qray(a.rays, slotT, mk3(b.to[0], b.to[1], b.to[2]), mk3(b.td[0], b.td[1], b.td[2]), -FLT_MAX, tag + 1);
+               store_qray(A()->rays, slotT, mk3(b.to[0], b.to[1], b.to[2]), mk3(b.td[0], b.td[1], b.td[2]), -FLT_MAX, tag + 1);
                out.child_refr = (int)slotT;
             }
             if (okR) {
-               store_qray(a.rays, slotR, mk3(b.ro[0], b.ro[1], b.ro[2]), mk3(b.rd[0], b.rd[1], b.rd[2]), -FLT_MAX, tag + 1);
+               store_qray(A()->rays, slotR, mk3(b.ro[0], b.ro[1], b.ro[2]), mk3(b.rd[0], b.rd[1], b.rd[2]), -FLT_MAX, tag + 1);
                out.child_refl = (int)slotR;
             }
             /* The shadow items go to the back of the list.  A lane with a bounce ray traces it itself, at once: the
@@ -1004,10 +1019,10 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
             if (nR + nT != cnt && lane == 0) stat_add(stats, ST_OVERFLOW, 1ULL);   /* the queue is full: the host retries with a larger one */
             cont_refl = okR; cont_refr = okT && !okR;
             /* a tile none of whose primaries spawns anything is shaded and resolved in one pass (k_resolve) */
-            if (a.tile_bounce && tag == 1 && (okR || okT)) a.tile_bounce[fd_div(idx, a.g.per_tile_div)] = 1u;
+            if (A()->tile_bounce && tag == 1 && (okR || okT)) A()->tile_bounce[fd_div(idx, A()->g.per_tile_div)] = 1u;
          }
       }
-      if (pend) *reinterpret_cast<float4 *>(a.recs + idx) = make_float4(out.refl, out.alpha, __int_as_float(out.child_refl), __int_as_float(out.child_refr));
+      if (pend) *reinterpret_cast<float4 *>(A()->recs + idx) = make_float4(out.refl, out.alpha, __int_as_float(out.child_refl), __int_as_float(out.child_refr));
       pend = false;
       if (cont_refl || cont_refr) {
          Ray r;
@@ -1031,7 +1046,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
       unsigned long long m_active = __ballot(active);
       int n_idle = 64 - __popcll(m_active);
       bool any_pend = OUT == OUT_CHAIN && __ballot(pend) != 0;
-      if ((n_idle >= a.refill_idle || m_active == 0) && (!exhausted || list_count > 0 || any_pend)) {
+      if ((n_idle >= refill_idle || m_active == 0) && (!exhausted || list_count > 0 || any_pend)) {
          const unsigned long long clk0 = COUNT ? wall_clock64() : 0ULL;
          if (COUNT) n_refills++;
          /* what the lanes that finished since the last refill spawn: a lane with a bounce ray goes on with it, the rest
@@ -1054,7 +1069,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
           * until it has seen them all dry.  The streams advance together, so the slots are still started in (nearly)
           * their order. */
          unsigned long long q_raw = 0;
-         if (need > 0 && lane == 0) q_raw = atomicAdd(a.next + (size_t)stream * 8, (unsigned long long)need);
+         if (need > 0 && lane == 0) q_raw = atomicAdd(A()->next + (size_t)stream * 8, (unsigned long long)need);
          /* What this wave stored earlier (list entries, queue entries, shaded points) is read back below, by other lanes
           * of the wave: those stores are complete first.  Only a refill that takes list entries reads anything back. */
          if (take > 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1086,7 +1101,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
                 * a stream seen dry stays dry; one seen live may be dry by the time the wave asks it, and then the wave
                 * looks again. */
                static_assert(RT_FETCH_STREAMS == 64, "one lane per stream");
-               const unsigned long long seen = __hip_atomic_load(a.next + (size_t)lane * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+               const unsigned long long seen = __hip_atomic_load(A()->next + (size_t)lane * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                const unsigned long long len_i = n_patches > lane ? ((n_patches - lane + RT_FETCH_STREAMS - 1) / RT_FETCH_STREAMS) * 64ULL : 0ULL;
                unsigned long long live = __ballot(seen < len_i) & ~(1ULL << stream);
                if (live == 0) exhausted = true;
@@ -1105,7 +1120,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
             if (OUT == OUT_CHAIN && own && (item.x & RT_SHADOW_ITEM)) {
                /* the feeler of light k for queue entry `node` (PointLight.h:18-20): from the light to the shaded point */
                const unsigned node = item.x & ~RT_SHADOW_ITEM, k = item.y;
-               unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.points + node);
+               unsigned long long *pp = reinterpret_cast<unsigned long long *>(A()->points + node);
                unsigned long long p01 = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                unsigned long long p23 = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                F3 P = mk3(__uint_as_float((unsigned)p01), __uint_as_float((unsigned)(p01 >> 32)), __uint_as_float((unsigned)p23));
@@ -1114,8 +1129,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
                Ray feeler; feeler.o = mk3(Lt.pos[0], Lt.pos[1], Lt.pos[2]); feeler.d = P - feeler.o;
                if ((int)k + 1 < sc.n_lights) { item.y = k + 1; put_back = true; }     /* same entry, next light */
                bool unneeded = false;
-               if (a.skip_unlit) {
-                  const unsigned fw = __hip_atomic_load(a.flag_words + (size_t)node * a.flag_stride + (k >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+               if (A()->skip_unlit) {
+                  const unsigned fw = __hip_atomic_load(A()->flag_words + (size_t)node * A()->flag_stride + (k >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   unneeded = ((fw >> (k & 31u)) & 1u) != 0u;
                }
                float slack;
@@ -1143,11 +1158,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
                   const unsigned long long q = q_base + (unsigned long long)(rank - take);
                   my = ((q >> 6) * RT_FETCH_STREAMS + my_stream) * 64ULL + (q & 63ULL);
                   have = q < q_len && my < n;
-                  if (have && OUT == OUT_CHAIN && a.tile_order) {
+                  if (have && OUT == OUT_CHAIN && A()->tile_order) {
                      /* the k-th tile to be started is tile_order[k] of this launch's tiles; where a sample's results
                       * are stored does not change */
-                     unsigned f = (unsigned)my, k = fd_div(f, a.g.per_tile_div);
-                     my = (unsigned long long)a.tile_order[k] * a.g.per_tile + (f - k * a.g.per_tile);
+                     unsigned f = (unsigned)my, k = fd_div(f, A()->g.per_tile_div);
+                     my = (unsigned long long)A()->tile_order[k] * A()->g.per_tile + (f - k * A()->g.per_tile);
                   }
                }
 #ifdef RT_DEBUG_REFILL_CLK
@@ -1155,21 +1170,21 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
 #endif
                if (have) {
                   QRay q;
-                  if (own) q = load_qray_written(a.rays, my);
+                  if (own) q = load_qray_written(A()->rays, my);
                   else if (OUT == OUT_CHAIN) {
                      /* generateCameraRays (kernel.cu:477-498) for sample slot `my`; the ray goes into the queue only if it
                       * hits something (the light sums need it then), see finish */
                      int X = 0, Y = 0;
-                     bool inside = slot_to_sample(a.g, (unsigned)my, X, Y);
+                     bool inside = slot_to_sample(A()->g, (unsigned)my, X, Y);
                      Ray pr; pr.o = mk3(0, 0, 0); pr.d = mk3(0, 0, 1);
-                     if (inside) pr = camera_ray(a.cam, a.g, X, Y);
+                     if (inside) pr = camera_ray(A()->cam, A()->g, X, Y);
                      q.ox = pr.o.x; q.oy = pr.o.y; q.oz = pr.o.z; q.to_beat = -FLT_MAX;
                      q.dx = pr.d.x; q.dy = pr.d.y; q.dz = pr.d.z; q.valid = inside ? 1 : 0;
                      if (!inside) {
                         /* a slot outside the frame: the result of a miss, no follow-up work */
-                        Hit h; h.prim = -1; h.t = FLT_MAX; a.hits[my] = h;
+                        Hit h; h.prim = -1; h.t = FLT_MAX; hits[my] = h;
                      }
-                  } else q = load_qray_rec(a.rays, my);
+                  } else q = load_qray_rec(A()->rays, my);
 #ifdef RT_DEBUG_REFILL_CLK
                   if (COUNT) { asm volatile("" : "+v"(q.dx), "+v"(q.ox)); dbg_d += wall_clock64() - clk0; }
 #endif
@@ -1210,11 +1225,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
          /* no ray enters the second tree during a burst (that happens in refills and leaf steps) */
          burst_filter = TWO && __ballot(active && (mode & MODE_FILTER)) != 0;
 #pragma unroll 1
-         for (int burst = 0; burst < a.node_burst; burst++) {
+         for (int burst = 0; burst < node_burst; burst++) {
             bool in_node = cur >= 0;                 /* idle lanes hold RT_CUR_IDLE */
             if (__ballot(in_node) == 0) break;
             /* enough lanes wait at a leaf: their step is worth its price now */
-            if ((int)__popcll(__ballot(cur < 0 && cur != RT_CUR_IDLE)) >= a.leaf_trigger) break;
+            if ((int)__popcll(__ballot(cur < 0 && cur != RT_CUR_IDLE)) >= leaf_trigger) break;
             if (COUNT) {
                wn++; if (active) ray_steps++;
                if (cur < 0) { if (cur == RT_CUR_IDLE) n_noray++; else n_leafwait++; }
@@ -1354,7 +1369,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
 #endif
    if (OUT == OUT_CHAIN) {
       /* what is left of the reserved queue entries reads as a miss (the light sums run over every entry below the tail) */
-      for (unsigned u = res_lo + lane; u < res_hi; u += 64) { Hit h; h.prim = -1; h.t = FLT_MAX; a.hits[u] = h; }
+      for (unsigned u = res_lo + lane; u < res_hi; u += 64) { Hit h; h.prim = -1; h.t = FLT_MAX; hits[u] = h; }
       for (int o = 32; o > 0; o >>= 1) n_skipped += __shfl_xor(n_skipped, o);
       for (int o = 32; o > 0; o >>= 1) n_unneeded += __shfl_xor(n_unneeded, o);
       if (lane == 0) {
@@ -2317,8 +2332,9 @@ static void launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs 
    a.spill = s->d_spill;
    const bool spill = stack_depth(s) > RT_LDS_STACK;
    const bool two = d.filter_root != RT_ROOT_EMPTY;
-#define RT_LAUNCH_TRACE2(O, C, S) do { if (two) hipLaunchKernelGGL((k_trace<O, C, S, true>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, d, a); \
-                                       else hipLaunchKernelGGL((k_trace<O, C, S, false>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, d, a); } while (0)
+   TraceKernArgs ka; ka.sc = d; ka.a = a;
+#define RT_LAUNCH_TRACE2(O, C, S) do { if (two) hipLaunchKernelGGL((k_trace<O, C, S, true>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, ka); \
+                                       else hipLaunchKernelGGL((k_trace<O, C, S, false>), dim3(blocks), dim3(RT_BLOCK), lds_bytes, stream, ka); } while (0)
 #define RT_LAUNCH_TRACE(O, C) do { if (spill) RT_LAUNCH_TRACE2(O, C, true); else RT_LAUNCH_TRACE2(O, C, false); } while (0)
    if (out_mode == OUT_CHAIN) { if (count) RT_LAUNCH_TRACE(OUT_CHAIN, true); else RT_LAUNCH_TRACE(OUT_CHAIN, false); }
    else { if (count) RT_LAUNCH_TRACE(OUT_HIT, true); else RT_LAUNCH_TRACE(OUT_HIT, false); }
