@@ -50,7 +50,7 @@ def timed_mean(pairs, steps):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     if os.path.exists(os.path.join(src, "bench.json")):
@@ -76,7 +76,7 @@ def main():
                        "note": "the last `timed_launches` launches of the kernel in the --kernel-trace run: the bench's timed steps"},
                       open(os.path.join(dst, f"{tag}_kernel_timed.json"), "w"), indent=1)
     summary = {}
-    for pas in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_l2"):
+    for pas in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_l2", "pmc_l1"):
         files = glob.glob(os.path.join(src, pas, "**", "*counter_collection.csv"), recursive=True)
         if not files:
             continue
