@@ -315,6 +315,18 @@ int rt_multi_set_camera(rt_multi *multi, const rt_camera *camera);
 int rt_multi_render(rt_multi *multi, const rt_render_params *params, uint8_t *out_rgba_host, rt_stats *stats);
 /* the same, the frame left in memory of the first device (out_rgba_dev: width*height*4 bytes there) */
 int rt_multi_render_device(rt_multi *multi, const rt_render_params *params, void *out_rgba_dev, rt_stats *stats);
+/* Several frames in flight on the device list (no counterpart in the reference; see rt_sequence_* below for one device):
+ * a driver made with rt_multi_create_pipelined keeps `frames_in_flight` (1 to 4) complete sets of replicas, streams and
+ * host threads.  rt_multi_submit hands the next frame (params and camera copied; camera NULL = the camera of the frame
+ * before it, or the scene's; out_rgba_dev: width*height*4 bytes on the first device, valid until the frame has been
+ * waited for) to the next set and returns; with frames_in_flight frames submitted and not waited for it fails with
+ * RT_ERR_BAD_ARGUMENT.  rt_multi_wait returns the oldest frame's status and statistics; frames complete in the order
+ * submitted.  The host's work per frame (waking the part threads, waiting for them, un-tiling, synchronising) then
+ * runs beside the next frame's launches.  rt_multi_render / _render_device / _set_camera need nothing in flight. */
+int rt_multi_create_pipelined(const rt_scene_desc *desc, const int *devices, int n_devices, int flags, int frames_in_flight, rt_multi **out);
+int rt_multi_frames_in_flight(const rt_multi *multi);
+int rt_multi_submit(rt_multi *multi, const rt_render_params *params, const rt_camera *camera, void *out_rgba_dev);
+int rt_multi_wait(rt_multi *multi, rt_stats *stats);
 
 /* ---- a frame sequence with several frames in flight --------------------- */
 /* The reference renders one frame per process (raytrace.cpp:18-56) and has nothing like this.  A caller that renders
@@ -322,10 +334,14 @@ int rt_multi_render_device(rt_multi *multi, const rt_render_params *params, void
  * with a stream and a host thread of its own; frames are dealt to the replicas in turn, so that the end of one frame
  * (the last waves of its traversal launch, its resolve pass, the host's wake-up) overlaps the start of the next.
  * Every frame is a whole rt_render_device frame: the same bytes and statistics.
- *   rt_sequence_submit  queues the next frame and returns at once: `params` and `camera` (NULL = the camera the replica
- *                       has: the scene's, or the last one submitted to it) are copied; `out_rgba_dev` (device memory,
+ *   rt_sequence_submit  queues the next frame and returns: `params` and `camera` (NULL = the camera of the frame submitted
+ *                       before it, or the scene's if none has been given yet) are copied; `out_rgba_dev` (device memory,
  *                       layout per params->out_layout) must stay valid until the frame has been waited for.  With
  *                       frames_in_flight frames queued or running it fails with RT_ERR_BAD_ARGUMENT: wait for one first.
+ *                       The first 6 x frames_in_flight frames of a frame size are rendered one at a time (every replica
+ *                       times its first frames to choose how it uses the second tree and to order its tiles, and a
+ *                       frame running beside them would spoil that): those submissions block until the frames before
+ *                       them have finished.
  *   rt_sequence_wait    waits for the oldest frame not yet waited for and returns its status and statistics
  *                       (RT_ERR_BAD_ARGUMENT when no frame is in flight).  Frames complete in the order submitted.
  * Submit and wait are for one calling thread at a time. */

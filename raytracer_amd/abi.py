@@ -116,7 +116,7 @@ EXPORTED_SYMBOLS = [
     "rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_create_host", "rt_scene_destroy", "rt_scene_get_info",
     "rt_scene_get_bvh", "rt_scene_set_camera", "rt_render", "rt_render_device", "rt_tile_count", "rt_tiles_live",
     "rt_sequence_create", "rt_sequence_destroy", "rt_sequence_frames_in_flight", "rt_sequence_submit", "rt_sequence_wait",
-    "rt_multi_create", "rt_multi_destroy", "rt_multi_device_count", "rt_multi_set_camera", "rt_multi_render", "rt_multi_render_device",
+    "rt_multi_create", "rt_multi_create_pipelined", "rt_multi_frames_in_flight", "rt_multi_submit", "rt_multi_wait", "rt_multi_destroy", "rt_multi_device_count", "rt_multi_set_camera", "rt_multi_render", "rt_multi_render_device",
     "rt_untile_device", "rt_trace_primary", "rt_frame_primary_hits", "rt_trace_rays", "rt_trace_rays_static", "rt_render_samples",
     "rt_parse_pov", "rt_scene_desc_free", "rt_load_bmp", "rt_write_tga", "launch_kernel",
 ]
@@ -161,6 +161,10 @@ def load_library(path=None):
     lib.rt_sequence_submit.argtypes = [vp, C.POINTER(RenderParams), C.POINTER(Camera), vp]
     lib.rt_sequence_wait.argtypes = [vp, C.POINTER(Stats)]
     lib.rt_multi_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(vp)]
+    lib.rt_multi_create_pipelined.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.rt_multi_frames_in_flight.argtypes = [vp]
+    lib.rt_multi_submit.argtypes = [vp, C.POINTER(RenderParams), C.POINTER(Camera), vp]
+    lib.rt_multi_wait.argtypes = [vp, C.POINTER(Stats)]
     lib.rt_multi_destroy.argtypes = [vp]
     lib.rt_multi_destroy.restype = None
     lib.rt_multi_device_count.argtypes = [vp]

@@ -250,13 +250,13 @@ class MultiScene:
     """One frame on several devices (rt_multi_*): a scene replica per entry of `devices`, tiles dealt round-robin,
     compact tile buffers gathered on the first device, un-tiled there.  A device may be listed more than once."""
 
-    def __init__(self, data: SceneData, devices, counters=False, fast_bvh=False):
+    def __init__(self, data: SceneData, devices, counters=False, fast_bvh=False, frames_in_flight=1):
         self._lib = abi.load_library()
         desc, keep = data.to_desc()
         devs = (C.c_int * len(devices))(*[int(d) for d in devices])
         h = C.c_void_p()
         flags = (abi.RT_SCENE_COUNTERS if counters else 0) | (abi.RT_SCENE_FAST_BVH if fast_bvh else 0)
-        _check(self._lib, self._lib.rt_multi_create(C.byref(desc), devs, len(devices), flags, C.byref(h)))
+        _check(self._lib, self._lib.rt_multi_create_pipelined(C.byref(desc), devs, len(devices), flags, frames_in_flight, C.byref(h)))
         self._h = h
         del keep
 
@@ -296,6 +296,23 @@ class MultiScene:
     def render_device(self, params, out_ptr):
         st = abi.Stats()
         _check(self._lib, self._lib.rt_multi_render_device(self._h, C.byref(params), C.c_void_p(out_ptr), C.byref(st)))
+        return st.as_dict()
+
+    def frames_in_flight(self):
+        return self._lib.rt_multi_frames_in_flight(self._h)
+
+    def submit(self, params, out_ptr, camera=None):
+        """Queue a frame into memory of the first device at `out_ptr`; camera = None or a dict of pos / up / right / look_at."""
+        cam = None
+        if camera is not None:
+            cam = abi.Camera()
+            for k in ("pos", "up", "right", "look_at"):
+                getattr(cam, k)[:] = [float(x) for x in camera[k]]
+        _check(self._lib, self._lib.rt_multi_submit(self._h, C.byref(params), C.byref(cam) if cam is not None else None, C.c_void_p(out_ptr)))
+
+    def wait(self):
+        st = abi.Stats()
+        _check(self._lib, self._lib.rt_multi_wait(self._h, C.byref(st)))
         return st.as_dict()
 
 

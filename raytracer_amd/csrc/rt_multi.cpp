@@ -13,6 +13,18 @@
  * A part has its own scene object (queues, counters, stream), so parts never share mutable state, and one host
  * thread per part drives it; the threads persist across frames.  The same device may appear more than once in the
  * device list: its parts then take turns on it, which is how the driver is tested on a one-GPU machine.
+ *
+ * Why the gather is N - 1 peer copies and not an RCCL collective: the parts are 1-4 MB, every part has exactly one
+ * destination, and the copies are already what a grouped send / receive would become on a fully connected node --
+ * one transfer per link, side by side -- without a communicator to set up per device list or a collective launch
+ * per frame (tens of microseconds each, against a frame of about a millisecond).  One process per GPU (bench.py under
+ * torch.distributed) has no peer pointers to copy through and gathers over RCCL.
+ *
+ * Frames in flight: a driver made with rt_multi_create_pipelined keeps that many complete sets of the above (a "core":
+ * replicas, streams, part threads, gather buffers) and a thread per core that runs whole frames; rt_multi_submit hands
+ * a frame to the next core and returns, rt_multi_wait returns the oldest.  The host's round trip per frame (wake the
+ * part threads, wait for them, un-tile, synchronise) is then off the critical path, and the end of one frame's
+ * launches overlaps the start of the next, as with rt_sequence on one device.
  */
 #include <hip/hip_runtime_api.h>
 
@@ -40,7 +52,7 @@ struct Part {
    std::thread worker;
 };
 
-struct rt_multi {
+struct Core {
    std::vector<Part> parts;
    void *d_parts = nullptr;          /* on parts[0].device: the gathered buffers, back to back */
    void *d_frame = nullptr;          /* on parts[0].device: the row-major frame */
@@ -53,6 +65,24 @@ struct rt_multi {
    bool quit = false;
    rt_render_params params;
    size_t part_bytes = 0;
+   /* the frame this core has been handed by rt_multi_submit, and the thread that runs it */
+   std::thread runner;
+   int job_state = 0;                /* 0 free, 1 queued or running, 2 done */
+   rt_render_params job_params;
+   rt_camera job_camera; bool job_has_camera = false;
+   void *job_out = nullptr;
+   rt_stats job_stats;
+   int job_status = RT_OK;
+   std::string job_error;
+};
+
+struct rt_multi {
+   std::vector<Core *> cores;
+   std::mutex mu;                    /* guards the cores' job_state */
+   std::condition_variable cv_job, cv_job_done;
+   bool quit = false;
+   unsigned long long submitted = 0, waited = 0;      /* frame k runs on core k mod cores.size() */
+   rt_camera camera; bool has_camera = false;         /* the camera a frame submitted without one is rendered with */
 };
 
 namespace {
@@ -74,7 +104,7 @@ size_t part_tile_bytes(int width, int height, int n_parts)
 }
 
 /* one frame of part k: render its tiles, send them to the first device */
-void render_part(rt_multi *m, int k)
+void render_part(Core *m, int k)
 {
    Part &p = m->parts[(size_t)k];
    p.status = RT_OK; p.error.clear();
@@ -100,7 +130,7 @@ void render_part(rt_multi *m, int k)
    MULTI_TRY(hipStreamSynchronize(p.stream), p);
 }
 
-void worker_loop(rt_multi *m, int k)
+void worker_loop(Core *m, int k)
 {
    unsigned long long seen = 0;
    for (;;) {
@@ -125,9 +155,7 @@ int fail(rt_multi *m, int code, const char *fmt, const char *detail)
    return code;
 }
 
-}  // namespace
-
-extern "C" void rt_multi_destroy(rt_multi *m)
+void core_destroy(Core *m)
 {
    if (!m) return;
    {
@@ -148,28 +176,26 @@ extern "C" void rt_multi_destroy(rt_multi *m)
    delete m;
 }
 
-extern "C" int rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_devices, int flags, rt_multi **out)
+/* one complete set of replicas, streams, part threads for the device list; returns null with the error text set */
+Core *core_create(const rt_scene_desc *desc, const int *devices, int n_devices, int flags, int visible, int *status)
 {
-   if (!desc || !out || n_devices <= 0 || n_devices > 64) { rt_set_error("rt_multi_create: bad argument"); return RT_ERR_BAD_ARGUMENT; }
-   *out = nullptr;
-   const int visible = rt_device_count();
-   if (visible <= 0) { rt_set_error("no HIP device: the render path has no CPU fallback"); return RT_ERR_NO_DEVICE; }
-   rt_multi *m = new (std::nothrow) rt_multi();
-   if (!m) { rt_set_error("rt_multi_create: out of memory"); return RT_ERR_BAD_ARGUMENT; }
+   Core *m = new (std::nothrow) Core();
+   if (!m) { rt_set_error("rt_multi_create: out of memory"); *status = RT_ERR_BAD_ARGUMENT; return nullptr; }
+   auto give_up = [&](int code, const std::string &why) { core_destroy(m); rt_set_error("rt_multi_create: %s", why.c_str()); *status = code; return (Core *)nullptr; };
    m->parts.resize((size_t)n_devices);
    for (int k = 0; k < n_devices; k++) {
       const int dev = devices ? devices[k] : k;
       if (dev < 0 || dev >= visible) {
-         char text[64]; snprintf(text, sizeof text, "%d (of %d visible)", dev, visible);
-         return fail(m, RT_ERR_BAD_ARGUMENT, "rt_multi_create: device %s out of range", text);
+         char text[96]; snprintf(text, sizeof text, "device %d (of %d visible) out of range", dev, visible);
+         return give_up(RT_ERR_BAD_ARGUMENT, text);
       }
       Part &p = m->parts[(size_t)k];
       p.device = dev;
       /* the scene is replicated: one copy of the flattened scene and its BVH per part, in that part's device memory */
       int rc = rt_scene_create(desc, dev, flags, &p.scene);
-      if (rc != RT_OK) { std::string why = rt_last_error(); return fail(m, rc, "rt_multi_create: %s", why.c_str()); }
+      if (rc != RT_OK) { std::string why = rt_last_error(); return give_up(rc, why); }
       if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) != hipSuccess)
-         return fail(m, RT_ERR_HIP, "rt_multi_create: %s", "stream creation failed");
+         return give_up(RT_ERR_HIP, "stream creation failed");
    }
    /* direct copies into the first device's memory: let every other device write there */
    for (int k = 1; k < n_devices; k++) {
@@ -181,21 +207,137 @@ extern "C" int rt_multi_create(const rt_scene_desc *desc, const int *devices, in
          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   /* the copy then goes through the host */
       }
    }
-   for (int k = 0; k < n_devices; k++) m->parts[(size_t)k].worker = std::thread(worker_loop, m, k);
+   try {
+      for (int k = 0; k < n_devices; k++) m->parts[(size_t)k].worker = std::thread(worker_loop, m, k);
+   } catch (...) {
+      return give_up(RT_ERR_BAD_ARGUMENT, "could not start the host threads");
+   }
+   return m;
+}
+
+int core_render(Core *m, const rt_render_params *params, uint8_t *out_host, void *out_dev, rt_stats *stats);
+
+/* the thread of a core: whole frames handed over by rt_multi_submit */
+void runner_loop(rt_multi *mm, Core *c)
+{
+   for (;;) {
+      {
+         std::unique_lock<std::mutex> lock(mm->mu);
+         mm->cv_job.wait(lock, [&] { return mm->quit || c->job_state == 1; });
+         if (mm->quit) return;
+      }
+      int rc = RT_OK;
+      if (c->job_has_camera) for (Part &p : c->parts) { rc = rt_scene_set_camera(p.scene, &c->job_camera); if (rc != RT_OK) break; }
+      memset(&c->job_stats, 0, sizeof c->job_stats);
+      if (rc == RT_OK) rc = core_render(c, &c->job_params, nullptr, c->job_out, &c->job_stats);
+      c->job_status = rc;
+      c->job_error = rc == RT_OK ? "" : rt_last_error();
+      {
+         std::lock_guard<std::mutex> lock(mm->mu);
+         c->job_state = 2;
+      }
+      mm->cv_job_done.notify_all();
+   }
+}
+
+}  // namespace
+
+extern "C" void rt_multi_destroy(rt_multi *m)
+{
+   if (!m) return;
+   {
+      std::lock_guard<std::mutex> lock(m->mu);
+      m->quit = true;
+   }
+   m->cv_job.notify_all();
+   for (Core *c : m->cores) if (c && c->runner.joinable()) c->runner.join();
+   for (Core *c : m->cores) core_destroy(c);
+   delete m;
+}
+
+extern "C" int rt_multi_create_pipelined(const rt_scene_desc *desc, const int *devices, int n_devices, int flags, int frames_in_flight, rt_multi **out)
+{
+   if (!desc || !out || n_devices <= 0 || n_devices > 64) { rt_set_error("rt_multi_create: bad argument"); return RT_ERR_BAD_ARGUMENT; }
+   *out = nullptr;
+   if (frames_in_flight < 1 || frames_in_flight > 4) { rt_set_error("rt_multi_create_pipelined: 1 to 4 frames in flight, not %d", frames_in_flight); return RT_ERR_BAD_ARGUMENT; }
+   const int visible = rt_device_count();
+   if (visible <= 0) { rt_set_error("no HIP device: the render path has no CPU fallback"); return RT_ERR_NO_DEVICE; }
+   rt_multi *m = new (std::nothrow) rt_multi();
+   if (!m) { rt_set_error("rt_multi_create: out of memory"); return RT_ERR_BAD_ARGUMENT; }
+   m->camera = desc->camera; m->has_camera = desc->has_camera != 0;
+   for (int f = 0; f < frames_in_flight; f++) {
+      int status = RT_OK;
+      Core *c = core_create(desc, devices, n_devices, flags, visible, &status);
+      if (!c) { std::string why = rt_last_error(); return fail(m, status, "%s", why.c_str()); }
+      m->cores.push_back(c);
+   }
+   try {
+      for (Core *c : m->cores) c->runner = std::thread(runner_loop, m, c);
+   } catch (...) {
+      return fail(m, RT_ERR_BAD_ARGUMENT, "rt_multi_create: %s", "could not start the host threads");
+   }
    *out = m;
    return RT_OK;
 }
 
-extern "C" int rt_multi_device_count(const rt_multi *m) { return m ? (int)m->parts.size() : 0; }
+extern "C" int rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_devices, int flags, rt_multi **out)
+{
+   return rt_multi_create_pipelined(desc, devices, n_devices, flags, 1, out);
+}
+
+extern "C" int rt_multi_device_count(const rt_multi *m) { return m && !m->cores.empty() ? (int)m->cores[0]->parts.size() : 0; }
+extern "C" int rt_multi_frames_in_flight(const rt_multi *m) { return m ? (int)m->cores.size() : 0; }
 
 extern "C" int rt_multi_set_camera(rt_multi *m, const rt_camera *camera)
 {
    if (!m || !camera) { rt_set_error("rt_multi_set_camera: null argument"); return RT_ERR_BAD_ARGUMENT; }
-   for (Part &p : m->parts) { int rc = rt_scene_set_camera(p.scene, camera); if (rc != RT_OK) return rc; }
+   {
+      std::lock_guard<std::mutex> lock(m->mu);
+      if (m->submitted != m->waited) { rt_set_error("rt_multi_set_camera: frames are in flight; pass the camera to rt_multi_submit instead"); return RT_ERR_BAD_ARGUMENT; }
+      m->camera = *camera; m->has_camera = true;
+   }
+   for (Core *c : m->cores) for (Part &p : c->parts) { int rc = rt_scene_set_camera(p.scene, camera); if (rc != RT_OK) return rc; }
    return RT_OK;
 }
 
-static int multi_render(rt_multi *m, const rt_render_params *params, uint8_t *out_host, void *out_dev, rt_stats *stats)
+extern "C" int rt_multi_submit(rt_multi *m, const rt_render_params *params, const rt_camera *camera, void *out_rgba_dev)
+{
+   if (!m || !params || !out_rgba_dev) { rt_set_error("rt_multi_submit: null argument"); return RT_ERR_BAD_ARGUMENT; }
+   {
+      std::lock_guard<std::mutex> lock(m->mu);
+      if (m->submitted - m->waited >= m->cores.size()) {
+         rt_set_error("rt_multi_submit: %d frames are in flight already: wait for one first", (int)m->cores.size());
+         return RT_ERR_BAD_ARGUMENT;
+      }
+      Core *c = m->cores[(size_t)(m->submitted % m->cores.size())];
+      /* a frame without a camera of its own is rendered with the driver's current one, whichever core it runs on */
+      if (camera) { m->camera = *camera; m->has_camera = true; }
+      c->job_params = *params; c->job_out = out_rgba_dev;
+      c->job_has_camera = m->has_camera; c->job_camera = m->camera;
+      c->job_state = 1;
+      m->submitted++;
+   }
+   m->cv_job.notify_all();
+   return RT_OK;
+}
+
+extern "C" int rt_multi_wait(rt_multi *m, rt_stats *stats)
+{
+   if (!m) { rt_set_error("rt_multi_wait: null argument"); return RT_ERR_BAD_ARGUMENT; }
+   std::unique_lock<std::mutex> lock(m->mu);
+   if (m->submitted == m->waited) { rt_set_error("rt_multi_wait: no frame is in flight"); return RT_ERR_BAD_ARGUMENT; }
+   Core *c = m->cores[(size_t)(m->waited % m->cores.size())];
+   m->cv_job_done.wait(lock, [&] { return c->job_state == 2; });
+   if (stats) *stats = c->job_stats;
+   const int rc = c->job_status;
+   if (rc != RT_OK) rt_set_error("%s", c->job_error.c_str());
+   c->job_state = 0;
+   m->waited++;
+   return rc;
+}
+
+namespace {
+int core_render(Core *m, const rt_render_params *params, uint8_t *out_host, void *out_dev, rt_stats *stats)
 {
    if (!m || !params || (!out_host && !out_dev)) { rt_set_error("rt_multi_render: null argument"); return RT_ERR_BAD_ARGUMENT; }
    if (params->width <= 0 || params->height <= 0) { rt_set_error("rt_multi_render: non-positive size"); return RT_ERR_BAD_ARGUMENT; }
@@ -269,6 +411,20 @@ static int multi_render(rt_multi *m, const rt_render_params *params, uint8_t *ou
    if (e != hipSuccess) { rt_set_error("rt_multi_render: %s", hipGetErrorString(e)); return RT_ERR_HIP; }
    if (stats) *stats = total;
    return RT_OK;
+}
+}  // namespace
+
+/* the one-call forms run on the first core, with nothing else in flight */
+static int multi_render(rt_multi *m, const rt_render_params *params, uint8_t *out_host, void *out_dev, rt_stats *stats)
+{
+   if (!m || m->cores.empty()) { rt_set_error("rt_multi_render: null argument"); return RT_ERR_BAD_ARGUMENT; }
+   {
+      std::lock_guard<std::mutex> lock(m->mu);
+      if (m->submitted != m->waited) { rt_set_error("rt_multi_render: frames submitted with rt_multi_submit are still in flight"); return RT_ERR_BAD_ARGUMENT; }
+   }
+   /* (frames that went through rt_multi_submit may have left the first core with an older camera than the driver's) */
+   if (m->has_camera) for (Part &p : m->cores[0]->parts) { int rc = rt_scene_set_camera(p.scene, &m->camera); if (rc != RT_OK) return rc; }
+   return core_render(m->cores[0], params, out_host, out_dev, stats);
 }
 
 extern "C" int rt_multi_render(rt_multi *m, const rt_render_params *params, uint8_t *out_rgba_host, rt_stats *stats)

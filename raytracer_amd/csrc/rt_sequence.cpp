@@ -51,6 +51,8 @@ struct rt_sequence {
     * size are rendered one at a time: this many more submissions wait until nothing else is running. */
    int serial_left = 0;
    long long size_key[5] = {0, 0, 0, 0, 0};
+   /* the camera a frame submitted without one is rendered with: the last one submitted, whichever replica got that frame */
+   rt_camera camera; bool has_camera = false;
 };
 
 namespace {
@@ -150,8 +152,9 @@ extern "C" int rt_sequence_submit(rt_sequence *q, const rt_render_params *params
       }
       Slot &s = q->slots[(size_t)(q->submitted % q->slots.size())];
       s.params = *params;
-      s.has_camera = camera != nullptr;
-      if (camera) s.camera = *camera;
+      if (camera) { q->camera = *camera; q->has_camera = true; }
+      s.has_camera = q->has_camera;
+      if (q->has_camera) s.camera = q->camera;
       s.out = out_rgba_dev;
       s.state = SLOT_QUEUED;
       q->submitted++;

@@ -119,3 +119,28 @@ def test_sequence_driver_refuses_more_frames_than_it_holds():
     assert bufs[0].cpu().numpy().tobytes() == bufs[1].cpu().numpy().tobytes() == bufs[2].cpu().numpy().tobytes()
     with pytest.raises(ra.RaytracerError):
         ra.Sequence(sd, frames_in_flight=0)
+
+
+def test_sequence_frame_without_a_camera_takes_the_one_before_it():
+    """rt_sequence_submit(camera = NULL) means "the camera of the frame before", whichever replica rendered that one."""
+    sd = ra.SceneData.load(os.path.join(G, "cornell.npz"))
+    w, h = 160, 120
+    base = {k: np.array(v, np.float32) for k, v in sd.camera.items()}
+    moved = dict(base, pos=base["pos"] + np.array([1.5, 0.5, 0.0], np.float32))
+    with ra.Scene(sd) as sc:
+        first, _ = sc.render(w, h, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, 2)
+        sc.set_camera(moved["pos"], moved["up"], moved["right"], moved["look_at"])
+        second, _ = sc.render(w, h, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, 2)
+    assert not np.array_equal(first, second)
+    p = ra.make_params(w, h, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, 2)
+    bufs = [torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    with ra.Sequence(sd, frames_in_flight=2) as seq:
+        got = []
+        for k, cam in enumerate((None, moved, None, None)):      # frames 2 and 3 land on different replicas
+            seq.submit(p, bufs[k].data_ptr(), cam)
+            seq.wait()
+            torch.cuda.synchronize()
+            got.append(bufs[k].cpu().numpy().reshape(h, w, 4))
+    assert np.array_equal(got[0], first)
+    for k in (1, 2, 3):
+        assert np.array_equal(got[k], second), k

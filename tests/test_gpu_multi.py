@@ -73,3 +73,55 @@ def test_cli_and_drop_in_split_a_frame(tmp_path):
         r = subprocess.run([dropin, str(out), "160", "120", "1", "phong"], capture_output=True, text=True, timeout=120, env={**os.environ, **env})
         assert r.returncode == 0, r.stdout + r.stderr
     assert open(a, "rb").read() == open(b, "rb").read()
+
+
+@pytest.mark.parametrize("parts, in_flight", [(2, 2), (3, 2), (4, 3)])
+def test_multi_frames_in_flight(parts, in_flight):
+    """rt_multi_submit / rt_multi_wait: a camera path with several frames in flight comes out frame by frame as the bytes
+    one device renders for each camera, in the order submitted; a frame submitted without a camera takes the one before
+    it (whichever set of replicas runs it); too many submissions and a wait with nothing in flight are refused."""
+    import torch
+    sd = ra.SceneData.load(os.path.join(G, "cornell.npz"))
+    w, h = 160, 120
+    cams = [dict(pos=[0.3 * k - 1.0, 5.0 + 0.1 * k, 15.5], up=[0, 1, 0], right=[1.3333, 0, 0], look_at=[0, 5, 0]) for k in range(7)]
+    p = ra.make_params(w, h, 1, ra.PHONG, abi.RT_JITTER_HASH, 5)
+    want = []
+    with ra.Scene(sd) as sc:
+        for c in cams:
+            sc.set_camera(c["pos"], c["up"], c["right"], c["look_at"])
+            f, _ = sc.render(w, h, 1, ra.PHONG, abi.RT_JITTER_HASH, seed=5)
+            want.append(f)
+    bufs = [torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda") for _ in range(in_flight)]
+    got, rays = [], []
+    with ra.MultiScene(sd, devices_for(parts), frames_in_flight=in_flight) as ms:
+        assert ms.frames_in_flight() == in_flight
+        with pytest.raises(ra.RaytracerError):
+            ms.wait()
+        def collect(k):
+            st = ms.wait()
+            torch.cuda.synchronize()
+            got.append(bufs[k % in_flight].cpu().numpy().reshape(h, w, 4).copy()); rays.append(st["rays_total"])
+        done = 0
+        for k, c in enumerate(cams):
+            if k - done >= in_flight:
+                collect(done); done += 1
+            # every second frame repeats the camera of the frame before it by passing none
+            ms.submit(p, bufs[k % in_flight].data_ptr(), None if k % 2 == 1 else c)
+        with pytest.raises(ra.RaytracerError):
+            for _ in range(in_flight + 1):
+                ms.submit(p, bufs[0].data_ptr(), None)      # one more than fits (the extra frames render into bufs[0]; drained below)
+        while done < len(cams):
+            collect(done); done += 1
+        # (drain what the refused burst did get in)
+        for _ in range(in_flight):
+            try:
+                ms.wait()
+            except ra.RaytracerError:
+                break
+        # the one-call form still works afterwards, with the camera the last submitted frame had
+        last, _ = ms.render(w, h, 1, ra.PHONG, abi.RT_JITTER_HASH, seed=5)
+    for k in range(len(cams)):
+        expect = want[k] if k % 2 == 0 else want[k - 1]
+        assert np.array_equal(got[k], expect), k
+    assert all(r > 0 for r in rays)
+    assert np.array_equal(last, want[6])
