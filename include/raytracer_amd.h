@@ -270,17 +270,18 @@ int rt_scene_set_camera(rt_scene *scene, const rt_camera *camera);
  * generate -> extend -> shadow -> shade (x depth) -> combine -> resolve -> D2H.
  * This is the body of launch_kernel after scene set-up (kernel.cu:735-760).
  * stats may be NULL. */
-int rt_render(const rt_scene *scene, const rt_render_params *params,
+int rt_render(rt_scene *scene, const rt_render_params *params,
               uint8_t *out_rgba_host, rt_stats *stats);
 
 /* Same, output left in DEVICE memory (`out_rgba_dev`, layout per
  * params->out_layout), work enqueued on `stream` (a hipStream_t, may be NULL
  * for the default stream).  Returns after the frame is complete: its statistics,
  * and the per-tile costs that order the next frame's tiles, come back with it.
- * A scene owns its working buffers (ray queue, spawn lists, tile order), so calls
- * on one scene must not overlap; callers that render concurrently use one scene each.
+ * A scene owns its working buffers (ray queue, spawn lists, tile order) and the rendering
+ * calls change them -- which is why they take a non-const scene --, so calls on one scene
+ * must not overlap; callers that render concurrently use one scene each.
  * Bytes needed: RT_OUT_FRAME width*height*4; RT_OUT_TILES rt_tile_count()*RT_TILE*RT_TILE*4. */
-int rt_render_device(const rt_scene *scene, const rt_render_params *params,
+int rt_render_device(rt_scene *scene, const rt_render_params *params,
                      void *out_rgba_dev, void *stream, rt_stats *stats);
 
 /* Number of tiles a (first, stride) selection covers for a width x height frame. */
@@ -356,7 +357,7 @@ int rt_sequence_wait(rt_sequence *seq, rt_stats *stats);
  * Per-sample closest hit of the primary rays (the first getClosestIntersection
  * of rayTrace, kernel.cu:531): prim_ids[i] (-1 = miss) and t[i] for sample
  * i = y*(width*s) + x; both host arrays of width*s*height*s entries. */
-int rt_trace_primary(const rt_scene *scene, const rt_render_params *params,
+int rt_trace_primary(rt_scene *scene, const rt_render_params *params,
                      int32_t *prim_ids_host, float *t_host);
 
 /* The same view of the frame the scene rendered last (rt_render / rt_render_device, whole launch): the closest hits its
@@ -369,7 +370,7 @@ int rt_frame_primary_hits(const rt_scene *scene, int32_t *prim_ids_host, float *
 
 /* Closest hit of arbitrary rays: rays_host = n x {ox,oy,oz,dx,dy,dz};
  * to_beat_host may be NULL (= -FLT_MAX for every ray, kernel.cu:84). */
-int rt_trace_rays(const rt_scene *scene, int64_t n, const float *rays_host,
+int rt_trace_rays(rt_scene *scene, int64_t n, const float *rays_host,
                   const float *to_beat_host, int32_t *prim_ids_host, float *t_host);
 
 /* rt_trace_rays for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
@@ -379,12 +380,12 @@ int rt_trace_rays(const rt_scene *scene, int64_t n, const float *rays_host,
  * on holds until the process ends.  More rays than that are rejected with RT_ERR_TOO_LARGE.  All calls on one device
  * share that array: calls that overlap on one device race (calls on different devices do not). */
 #define RT_TRACE_RAYS_STATIC_MAX 524288
-int rt_trace_rays_static(const rt_scene *scene, int64_t n, const float *rays_host,
+int rt_trace_rays_static(rt_scene *scene, int64_t n, const float *rays_host,
                          const float *to_beat_host, int32_t *prim_ids_host, float *t_host);
 
 /* Per-sample clamped float RGB, the reference's antiAliasBuffer
  * (kernel.cu:537-541): n_samples x 3 floats, host. */
-int rt_render_samples(const rt_scene *scene, const rt_render_params *params,
+int rt_render_samples(rt_scene *scene, const rt_render_params *params,
                       float *rgb_host, rt_stats *stats);
 
 /* ---- host-side pieces either side of the path -------------------------- */
