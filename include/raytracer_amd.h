@@ -373,12 +373,14 @@ int rt_frame_primary_hits(const rt_scene *scene, int32_t *prim_ids_host, float *
 int rt_trace_rays(rt_scene *scene, int64_t n, const float *rays_host,
                   const float *to_beat_host, int32_t *prim_ids_host, float *t_host);
 
-/* rt_trace_rays for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as rt_trace_rays, but
- * the call makes no hipMalloc / hipFree: its working memory (counters, the staged rays, the queue entries, the hits)
- * is an array inside the library, RT_TRACE_RAYS_STATIC_MAX rays' worth (36 MB), which every device the library runs
- * on holds until the process ends.  More rays than that are rejected with RT_ERR_TOO_LARGE.  All calls on one device
- * share that array: calls that overlap on one device race (calls on different devices do not). */
+/* rt_trace_rays for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc).
+ * No counterpart in the reference.  Same arguments and results as rt_trace_rays -- host arrays in, host arrays out,
+ * the call returns when the results are there -- but it makes no hipMalloc / hipFree: its working memory (counters, the
+ * staged rays, the queue entries, the hits) is an array inside the library, RT_TRACE_RAYS_STATIC_MAX rays' worth
+ * (36 MB), which every device the library runs on holds until the process ends.  More rays than that are rejected with
+ * RT_ERR_TOO_LARGE.  All scenes on one device share that device's array: calls from several threads on one device take
+ * turns (the library serialises them), calls on different devices run side by side.  It takes no stream and
+ * synchronises, so it is not for use inside a HIP graph capture. */
 #define RT_TRACE_RAYS_STATIC_MAX 524288
 int rt_trace_rays_static(rt_scene *scene, int64_t n, const float *rays_host,
                          const float *to_beat_host, int32_t *prim_ids_host, float *t_host);

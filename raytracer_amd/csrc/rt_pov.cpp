@@ -489,8 +489,8 @@ bool parse_file(Scanner &in, SceneOut &out)
 template <class T> const T *release(const std::vector<T> &v)
 {
    T *p = (T *)malloc(sizeof(T) * (v.size() ? v.size() : 1));
-   if (!v.empty()) memcpy(p, v.data(), sizeof(T) * v.size());
-   return p;
+   if (p && !v.empty()) memcpy(p, v.data(), sizeof(T) * v.size());
+   return p;      /* null when out of memory: rt_parse_pov checks */
 }
 
 } // namespace

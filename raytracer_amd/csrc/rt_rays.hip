@@ -54,12 +54,30 @@ static RayWork raywork_carve(char *base, size_t n)
 }
 
 /* The body both entry points share: nothing here allocates. */
+static int trace_rays_queued(rt_scene *s, const RayWork &w, int64_t n, const float *rays_host, const float *to_beat_host,
+                             int32_t *prim_host, float *t_host, hipStream_t S, unsigned long long *aborted);
+
 static int trace_rays_in(rt_scene *s, const RayWork &w, int64_t n, const float *rays_host, const float *to_beat_host,
                          int32_t *prim_host, float *t_host)
 {
+   hipStream_t S = nullptr;
+   unsigned long long aborted[RT_STAT_REPL];
+   memset(aborted, 0, sizeof aborted);
+   int rc = trace_rays_queued(s, w, n, rays_host, to_beat_host, prim_host, t_host, S, aborted);
+   /* whatever was queued before a failure may still be writing into the caller's arrays (or `aborted`): it ends first */
+   hipError_t e = hipStreamSynchronize(S);
+   if (rc != RT_OK) return rc;
+   if (e != hipSuccess) { rt_set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e)); return RT_ERR_HIP; }
+   for (int r = 0; r < RT_STAT_REPL; r++)
+      if (aborted[r]) { rt_set_error("traversal aborted: step cap reached (corrupt scene?)"); return RT_ERR_HIP; }
+   return RT_OK;
+}
+
+static int trace_rays_queued(rt_scene *s, const RayWork &w, int64_t n, const float *rays_host, const float *to_beat_host,
+                             int32_t *prim_host, float *t_host, hipStream_t S, unsigned long long *aborted)
+{
    size_t lds_bytes = 0;
    { int rc = rt_trace_lds_bytes(s, &lds_bytes); if (rc != RT_OK) return rc; }
-   hipStream_t S = nullptr;
    HIP_TRY(hipMemsetAsync(w.ctr, 0, sizeof(unsigned long long) * (RT_CTR_WORDS + ST_COUNT * RT_STAT_REPL), S));
    HIP_TRY(hipMemcpyAsync(w.raw, rays_host, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, S));
    if (to_beat_host) HIP_TRY(hipMemcpyAsync(w.beat, to_beat_host, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, S));
@@ -72,11 +90,7 @@ static int trace_rays_in(rt_scene *s, const RayWork &w, int64_t n, const float *
    HIP_TRY(hipGetLastError());
    HIP_TRY(hipMemcpyAsync(prim_host, w.prim_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, S));
    HIP_TRY(hipMemcpyAsync(t_host, w.t_out, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, S));
-   unsigned long long aborted[RT_STAT_REPL];
-   HIP_TRY(hipMemcpyAsync(aborted, w.stats + ST_ABORTED * RT_STAT_REPL, sizeof aborted, hipMemcpyDeviceToHost, S));
-   HIP_TRY(hipStreamSynchronize(S));
-   for (int r = 0; r < RT_STAT_REPL; r++)
-      if (aborted[r]) { rt_set_error("traversal aborted: step cap reached (corrupt scene?)"); return RT_ERR_HIP; }
+   HIP_TRY(hipMemcpyAsync(aborted, w.stats + ST_ABORTED * RT_STAT_REPL, sizeof(unsigned long long) * RT_STAT_REPL, hipMemcpyDeviceToHost, S));
    return RT_OK;
 }
 
@@ -109,6 +123,7 @@ static __device__ __align__(256) unsigned char scratch[RT_RAYWORK_HEADER + (28 +
 #define RT_MAX_DEVICES 64
 static std::mutex g_scratch_mutex;
 static char *g_scratch_ptr[RT_MAX_DEVICES];      /* per device: the address of `scratch` there, once looked up */
+static std::mutex g_scratch_in_use[RT_MAX_DEVICES];   /* per device: held for the length of a call that works in `scratch` */
 
 /* with `device` current: the device address of that device's copy of `scratch` */
 int rt_scratch_address(int device, char **out)
@@ -138,6 +153,8 @@ extern "C" int rt_trace_rays_static(rt_scene *s, int64_t n, const float *rays_ho
    char *base = nullptr;
    { int rc = rt_scratch_address(s->device, &base); if (rc != RT_OK) return rc; }
    if (raywork_bytes((size_t)n) > sizeof scratch) { rt_set_error("internal: static working memory too small"); return RT_ERR_TOO_LARGE; }
+   /* every scene on a device shares that device's array: calls from several threads take turns */
+   std::lock_guard<std::mutex> in_use(g_scratch_in_use[s->device]);
    return trace_rays_in(s, raywork_carve(base, (size_t)n), n, rays_host, to_beat_host, prim_host, t_host);
 }
 

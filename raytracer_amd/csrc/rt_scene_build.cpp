@@ -23,6 +23,7 @@
 #include <map>
 #include <string>
 #include <algorithm>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -359,9 +360,14 @@ struct SahBuilder {
          int r_local = -1;
          bool threaded = true;
          std::thread worker;
-         try { worker = std::thread([&]() { r_local = other.build(mid, last, depth_left - 1, par - 1); }); } catch (...) { threaded = false; }
-         l = build(first, mid, depth_left - 1, par - 1);
+         bool worker_failed = false;
+         try {
+            worker = std::thread([&]() { try { r_local = other.build(mid, last, depth_left - 1, par - 1); } catch (...) { worker_failed = true; } });
+         } catch (...) { threaded = false; }
+         /* (whatever this half throws, the other half's thread is joined before the exception goes on) */
+         try { l = build(first, mid, depth_left - 1, par - 1); } catch (...) { if (threaded) worker.join(); throw; }
          if (threaded) worker.join(); else r_local = other.build(mid, last, depth_left - 1, 0);
+         if (worker_failed) throw std::bad_alloc();
          const int off = (int)pool.size();
          for (TreeNode nd : other_pool) {
             if (nd.prim < 0) { nd.left += off; nd.right += off; }

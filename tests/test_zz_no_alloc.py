@@ -46,3 +46,43 @@ def test_static_variant_rejects_too_many_rays():
         assert e.value.code == abi.RT_ERR_TOO_LARGE
         p, t = sc.trace_rays(rays[:abi.RT_TRACE_RAYS_STATIC_MAX], static=True)       # the limit itself is accepted
         assert len(p) == abi.RT_TRACE_RAYS_STATIC_MAX
+
+
+def test_static_variant_allocates_no_device_memory():
+    """The device's free memory (hipMemGetInfo, through torch) is the same before and after calls of the static variant.
+    Several threads calling it on one device, each with a scene of its own, take turns and get the right answers."""
+    import threading
+    import torch
+    sd = ra.SceneData.load(os.path.join(G, "cornell.npz"))
+    with ra.Scene(sd) as sc:
+        rays, beat = random_rays(100_000, 9)
+        want_p, want_t = sc.trace_rays(rays, beat)
+        sc.trace_rays(rays, beat, static=True)                  # (first use: whatever the runtime sets up lazily is set up)
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        for _ in range(3):
+            p, t = sc.trace_rays(rays, beat, static=True)
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free1 == free0
+        assert np.array_equal(p, want_p) and np.array_equal(t.view(np.uint32), want_t.view(np.uint32))
+    # two scenes on the one device share the array: concurrent calls must not corrupt each other
+    scenes = [ra.Scene(sd), ra.Scene(sd)]
+    out, errors = [None, None], []
+
+    def work(i):
+        try:
+            for _ in range(4):
+                out[i] = scenes[i].trace_rays(rays, beat, static=True)
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for s in scenes:
+        s.close()
+    assert not errors
+    for i in range(2):
+        assert np.array_equal(out[i][0], want_p) and np.array_equal(out[i][1].view(np.uint32), want_t.view(np.uint32))
