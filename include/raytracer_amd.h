@@ -194,6 +194,9 @@ typedef struct rt_stats {
     * their point's colour: Phong frames (PhongShader.h:7-25), a light behind the surface whose mirror direction points
     * away from the eye.  Counted in rays_shadow like the rest (the reference walks its tree for each of them) */
    uint64_t shadows_unneeded;
+   /* RT_SCENE_COUNTERS: of hits_contested, the rays whose walk of the reference's tree left out every subtree without one
+    * of the few primitives that can change its outcome (the others made the walk in full) */
+   uint64_t hits_guided;
 } rt_stats;
 
 typedef struct rt_scene_info {

@@ -96,7 +96,7 @@ struct SpawnRec {
 
 enum { ST_SHADOW_SKIPPED = 0, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES,
        ST_NODE_VISITS, ST_PRIM_TESTS, ST_TIES, ST_WAVE_NODE_STEPS, ST_WAVE_LEAF_STEPS,          /* extend launches */
-       ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_CERT_OK, ST_CERT_RIVAL, ST_CERT_UNREACHED, ST_SHADOW_CERT, ST_SHADOW_UNNEEDED, ST_LEAF_WAIT, ST_NO_RAY, ST_REFILLS, ST_CLK_REFILL, ST_CLK_NODE, ST_CLK_LEAF, ST_CLK_WAVE,
+       ST_NODE_VISITS_SHADOW, ST_PRIM_TESTS_SHADOW, ST_TIES_SHADOW, ST_CERT_OK, ST_CERT_RIVAL, ST_CERT_UNREACHED, ST_GUIDED, ST_SHADOW_CERT, ST_SHADOW_UNNEEDED, ST_LEAF_WAIT, ST_NO_RAY, ST_REFILLS, ST_CLK_REFILL, ST_CLK_NODE, ST_CLK_LEAF, ST_CLK_WAVE,
        ST_ABORTED, ST_MAX_RAY_STEPS, ST_MAX_LIST, ST_OVERFLOW, ST_LIST_OVERFLOW,
        ST_CLOCK_FIRST_START, ST_CLOCK_LAST_EXIT, ST_CLOCK_EXIT_SUM, ST_WAVES,
 #ifdef RT_DEBUG_EXIT_HIST
@@ -129,7 +129,18 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2, MODE_KIND = 3,
        /* a feeler in the second tree, about the primitives it has met in front of its target (see the leaf step) */
        MODE_BAND = 16,      /* one within EPSILON of the target: the reference's walk would stop at it and report "lit" */
        /* a feeler being set up (MODE_SETUP) whose answer cannot change its point's colour: see TraceArgs::skip_unlit */
-       MODE_UNNEEDED = 32 };
+       MODE_UNNEEDED = 32,
+       /* a closest-hit ray on the reference's walk that knows which few leaves can change that walk's outcome and leaves
+        * out every subtree that holds none of them (see finish() and the node step) */
+       MODE_GUIDED = 64 };
+/* The leaves such a ray keeps: at most RT_GUIDE_K, per lane in LDS (a count, the leaves, the largest parameter among
+ * them).  They are all the primitives the ray met in the second tree; the walk is guided only if every one of them lies
+ * within RT_GUIDE_NEAR of the nearest.  The second tree was searched RT_LOOK_ABS behind the nearest hit (less the
+ * RT_SLACK_MAX a sphere's parameter may be off by), so every other primitive the ray meets is more than EQUAL_EPSILON
+ * behind every kept one: it ties with none of them and is never preferred to one. */
+#define RT_GUIDE_K 4
+#define RT_GUIDE_WORDS (RT_GUIDE_K + 2)
+#define RT_GUIDE_NEAR 0.03f
 /* How far beyond the nearest hit so far a closest-hit ray still looks in the second tree: every box that starts
  * within RT_LOOK_ABS + t * RT_LOOK_REL behind it.  It has to know of every primitive within EQUAL_EPSILON of its
  * nearest one; the rest of the margin is allowance for a primitive's computed parameter lying in front of where its
@@ -165,6 +176,7 @@ enum { MODE_EXTEND = 0, MODE_SHADOW = 1, MODE_SETUP = 2, MODE_KIND = 3,
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 4  /* resident waves per SIMD the traversal kernel is compiled for (128 registers per lane) */
 #endif
+#define RT_OLD_RAY 150u      /* a ray that has cost more than this raises its wave's priority (k_trace) */
 #define RT_LONG_FEELER 128u  /* a feeler of a primary that cost more than this raises its tile's cost (k_trace) */
 #define RT_ORDER_CLASSES 1024 /* classes of tile cost that decide the order in which a frame's tiles are started */
 #define RT_ORDER_MEAN_WEIGHT 0  /* what a tile's mean chain adds to its longest one in that cost (it was 4 while tiles nothing can be seen through still
@@ -209,6 +221,8 @@ struct TraceArgs {
    unsigned *tile_bounce;       /* when non-null: per tile of the launch (zeroed), set when a primary of the tile spawns a bounce ray */
    unsigned *tile_hit;          /* when non-null: per tile of the launch (zeroed), set when a primary of the tile hits something */
    unsigned *tile_cost;         /* when non-null: two words per tile of the launch (zeroed); the first is raised to the cost of a long feeler of one of the tile's primaries */
+   int guide;                   /* the reference's tree carries each node's range of leaves and its boxes are nested: contested closest-hit rays may walk it guided */
+   float tree_lo[3], tree_hi[3];   /* the box that holds both boxes of that tree's root: a ray that starts outside it starts inside no box of the tree */
 };
 
 __device__ __forceinline__ QRay load_qray_rec(const QRay *q, unsigned long long i)

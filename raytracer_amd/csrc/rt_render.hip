@@ -137,7 +137,8 @@ int rt_trace_lds_bytes(const rt_scene *s, size_t *out)
    /* the stack holds at most one deferred sibling per internal level; RT_LDS_STACK of them live in LDS */
    int depth = rt_stack_depth(s);
    if (depth > RT_LDS_STACK) depth = RT_LDS_STACK;
-   *out = sizeof(StackEntry) * (size_t)RT_BLOCK * (size_t)depth;
+   /* in front of the stacks: the leaves a guided walk keeps, RT_GUIDE_WORDS words per lane */
+   *out = sizeof(StackEntry) * (size_t)RT_BLOCK * (size_t)depth + sizeof(unsigned) * (size_t)RT_BLOCK * RT_GUIDE_WORDS;
    return RT_OK;
 }
 
@@ -166,6 +167,8 @@ void rt_launch_trace(const rt_scene *s, int out_mode, bool count, TraceArgs a, u
    a.reserve = s->reserve;
    if (!a.stats) a.stats = s->d_stats;
    a.spill = s->d_spill;
+   a.guide = s->guide_ok ? 1 : 0;
+   for (int j = 0; j < 3; j++) { a.tree_lo[j] = s->tree_lo[j]; a.tree_hi[j] = s->tree_hi[j]; }
    const bool spill = rt_stack_depth(s) > RT_LDS_STACK;
    const bool two = d.filter_root != RT_ROOT_EMPTY;
    TraceKernArgs ka; ka.sc = d; ka.a = a;
@@ -697,7 +700,7 @@ static int render_impl(rt_scene *s, const rt_render_params *p, int view, void *o
    st.wave_node_steps = sum_stat(s->h_stats, ST_WAVE_NODE_STEPS); st.wave_leaf_steps = sum_stat(s->h_stats, ST_WAVE_LEAF_STEPS);
    st.lane_steps_at_leaf = sum_stat(s->h_stats, ST_LEAF_WAIT); st.lane_steps_no_ray = sum_stat(s->h_stats, ST_NO_RAY);
    st.wave_refills = sum_stat(s->h_stats, ST_REFILLS);
-   st.hits_certified = sum_stat(s->h_stats, ST_CERT_OK); st.hits_contested = sum_stat(s->h_stats, ST_CERT_RIVAL);
+   st.hits_certified = sum_stat(s->h_stats, ST_CERT_OK); st.hits_contested = sum_stat(s->h_stats, ST_CERT_RIVAL); st.hits_guided = sum_stat(s->h_stats, ST_GUIDED);
    st.hits_unreached = sum_stat(s->h_stats, ST_CERT_UNREACHED);
    st.shadows_certified = sum_stat(s->h_stats, ST_SHADOW_CERT);
    st.shadows_unneeded = sum_stat(s->h_stats, ST_SHADOW_UNNEEDED);

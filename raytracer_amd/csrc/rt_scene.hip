@@ -172,6 +172,32 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
          if (d_nodes[k].left < 0) leaf_parent[(size_t)~d_nodes[k].left] = (int32_t)k;
          if (d_nodes[k].right < 0) leaf_parent[(size_t)~d_nodes[k].right] = (int32_t)k;
       }
+   /* Each node of the reference's tree is given the range of leaves below it, in the two spare words of its record.  The
+    * primitives are numbered in the order of that tree's leaves and the nodes parent, left subtree, right subtree, every
+    * node with two children: a subtree with m nodes holds m + 1 consecutive leaves.  A guided walk (k_trace) relies on
+    * exactly that and is only allowed when it has been checked here. */
+   s->guide_ok = false;
+   if (n_filter > 0 && n_tree > 0 && h.root >= 0) {
+      bool ok = true;
+      auto lo_of = [&](int32_t c) { return c < 0 ? ~c : d_nodes[(size_t)c].pad[0]; };
+      auto hi_of = [&](int32_t c) { return c < 0 ? ~c + 1 : d_nodes[(size_t)c].pad[1]; };
+      for (size_t k = n_tree; k-- > 0 && ok;) {
+         rt_bvh_node &n = d_nodes[k];
+         if ((n.left >= 0 && (size_t)n.left <= k) || (n.right >= 0 && (size_t)n.right <= k) || (n.left >= 0 && (size_t)n.left != k + 1)) { ok = false; break; }
+         n.pad[0] = lo_of(n.left); n.pad[1] = hi_of(n.right);
+         ok = hi_of(n.left) == lo_of(n.right) && n.pad[0] < n.pad[1];
+         /* the left subtree's nodes are k+1 .. right-1 when the right child is a node: one leaf more than nodes */
+         if (ok && n.left >= 0 && n.right >= 0) ok = hi_of(n.left) - lo_of(n.left) == (n.right - n.left) + 1;
+      }
+      if (ok) ok = d_nodes[(size_t)h.root].pad[0] == 0 && d_nodes[(size_t)h.root].pad[1] == (int32_t)np_ && h.root == 0;
+      if (!ok) for (size_t k = 0; k < n_tree; k++) d_nodes[k].pad[0] = d_nodes[k].pad[1] = 0;
+      else {
+         const rt_bvh_node &r = d_nodes[(size_t)h.root];
+         for (int j = 0; j < 3; j++) { s->tree_lo[j] = std::min(r.lmin[j], r.rmin[j]); s->tree_hi[j] = std::max(r.lmax[j], r.rmax[j]); }
+         for (int j = 0; j < 3; j++) if (!(s->tree_lo[j] <= s->tree_hi[j])) ok = false;
+      }
+      s->guide_ok = ok;
+   }
    enum { N_ARR = 11 };
    size_t off[N_ARR + 1], sizes[N_ARR] = {
       sizeof(rt_bvh_node) * d_nodes.size(), sizeof(rt_dev_prim) * (size_t)h.n_prims,
@@ -230,6 +256,7 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
          }
       }
       s->d.verify_jump = nested && rt_env_int("RT_VERIFY_JUMP", 1, true) ? 1 : 0;
+      s->guide_ok = s->guide_ok && nested && rt_env_int("RT_GUIDE", 1, true) != 0;
    }
    s->d.sphere_coeff = h.sphere_coeff; s->d.origin_coeff = 9.5367431640625e-7f;
    /* (for measurements: what the two margins cost) */

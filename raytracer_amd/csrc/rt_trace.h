@@ -338,7 +338,10 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
    /* The per-lane stack of deferred siblings: one column per lane in LDS.  A tree deeper than RT_LDS_STACK levels
     * (SPILL) keeps the entries beyond that in global memory, a column per lane of the launch, so that deep trees do
     * not cost the four workgroups per CU their LDS; a ray rarely defers that many siblings at once. */
-   StackEntry *stack = lds_stack + threadIdx.x;
+   /* in front of the stacks: RT_GUIDE_WORDS words per lane for the leaves a guided walk keeps (word w of a lane is
+    * guide[w * RT_BLOCK]): their number, the leaves, the largest parameter among them */
+   unsigned *const guide = reinterpret_cast<unsigned *>(lds_stack) + threadIdx.x;
+   StackEntry *stack = lds_stack + (RT_GUIDE_WORDS * RT_BLOCK * sizeof(unsigned)) / sizeof(StackEntry) + threadIdx.x;
    const int stride = RT_BLOCK;
    StackEntry *const spill = SPILL ? A()->spill + ((size_t)blockIdx.x * RT_BLOCK + threadIdx.x) : nullptr;
    const size_t spill_stride = SPILL ? (size_t)gridDim.x * RT_BLOCK : 0;
@@ -392,6 +395,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
    bool wave_par = false;              /* wave-uniform: some lane may hold a ray with a parallel axis */
    bool wave_lit = false;              /* wave-uniform: some lane holds a ray the short box test is not valid for */
    bool burst_filter = false;          /* wave-uniform: some lane of the current burst of node steps is in the second tree */
+   bool burst_guided = false;          /* wave-uniform: some lane of the current burst makes a guided walk */
    RayCtx c;
    c.r.o = mk3(0, 0, 0); c.r.d = mk3(1, 1, 1); c.yx = c.yy = c.yz = 1.0f; c.par = 0; c.fast = true; c.wide = 0.0f;
    float t = FLT_MAX, toBeat = -FLT_MAX;
@@ -421,6 +425,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
    unsigned n_unneeded = 0;                             /* OUT_CHAIN: feelers that stopped after their own-surface test because their answer cannot matter */
    unsigned n_shadow_cert = 0;                          /* COUNT only: feelers reported "shadowed" from the second tree and one path of the reference's */
    unsigned n_cert = 0, n_rival = 0, n_unreached = 0;   /* COUNT only: how this lane's closest-hit rays left the second tree with a hit */
+   unsigned n_guided = 0;                               /* COUNT only: of n_rival, those that went on guided */
    unsigned n_leafwait = 0, n_noray = 0, n_refills = 0;   /* COUNT only: node steps this lane sat out at a leaf / without a ray; refills of the wave */
 
    /* a ray is finished: scan the planes unless it left early, write its result */
@@ -434,7 +439,27 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
          const bool alone = t > 2.0f * RT_EQ_EPS && !(t + RT_EQ_EPS > toBeat);
          if (COUNT) { if (alone) n_cert++; else n_rival++; }
          if (alone) { mode = MODE_EXTEND | MODE_VERIFY; toBeat = __int_as_float(sc.leaf_parent[closest]); cur = sc.root; }
-         else { mode = MODE_EXTEND; toBeat = -FLT_MAX; t = FLT_MAX; closest = -1; cur = sc.root; sp = 0; }
+         else {
+            /* With a rival the order of the reference's walk decides, and that walk is made.  If the second tree has shown
+             * the ray every primitive that can take part in the decision -- a few, all within RT_GUIDE_NEAR of the
+             * nearest, while everything else the ray meets is at least RT_LOOK_ABS - RT_SLACK_MAX behind the nearest --
+             * the walk may leave out the subtrees that hold none of them.  What it would do in there changes nothing:
+             * a primitive behind the origin is never accepted (t stays above 2 EQUAL_EPSILON); one of the far ones is
+             * accepted only while the walk holds nothing or another far one, ties with none of the kept ones and loses to
+             * each of them; and while the walk holds a far one it enters the same boxes with kept leaves as while it
+             * holds nothing, since those boxes start in front of the kept leaves' parameters (the ray starts outside
+             * every box of the tree: it starts outside the root's two, and the boxes are nested). */
+            bool guided = false;
+            if (A()->guide && t > 2.0f * RT_EQ_EPS) {
+               const unsigned kept = guide[0];
+               const float farthest = __uint_as_float(guide[(RT_GUIDE_K + 1) * RT_BLOCK]);
+               const bool outside = !(c.r.o.x > A()->tree_lo[0] && c.r.o.x < A()->tree_hi[0] && c.r.o.y > A()->tree_lo[1] && c.r.o.y < A()->tree_hi[1] &&
+                                      c.r.o.z > A()->tree_lo[2] && c.r.o.z < A()->tree_hi[2]);
+               guided = kept <= RT_GUIDE_K && farthest <= t + RT_GUIDE_NEAR && outside;
+            }
+            if (COUNT && guided) n_guided++;
+            mode = guided ? (MODE_EXTEND | MODE_GUIDED) : MODE_EXTEND; toBeat = -FLT_MAX; t = FLT_MAX; closest = -1; cur = sc.root; sp = 0;
+         }
          return;
       }
       if (TWO && OUT == OUT_CHAIN && (mode & (MODE_KIND | MODE_FILTER)) == (MODE_SHADOW | MODE_FILTER) && closest >= 0) {
@@ -572,6 +597,25 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
       asm volatile("" : : "v"(tail.z), "v"(tail.w));
       const float inf = __builtin_inff();
       float l = above_zero(left) ? left : inf, r = above_zero(right) ? right : inf;
+      if (TWO && OUT == OUT_CHAIN && burst_guided) {
+         /* A guided walk: a child whose subtree holds none of the kept leaves is treated as not ahead -- never entered,
+          * never deferred.  The node's record carries the range of leaves below it (the leaves are numbered in the
+          * tree's order); the left child's part of it ends after the one leaf, or before the right child's one leaf, or
+          * after one leaf more than the left subtree has nodes. */
+         if (mode & MODE_GUIDED) {
+            const int lo = tail.z, hi = tail.w;
+            const int split = ch.x < 0 ? lo + 1 : (ch.y < 0 ? hi - 1 : lo + (ch.y - ch.x) + 1);
+            const int kept = (int)guide[0];
+            bool in_l = false, in_r = false;
+#pragma unroll
+            for (int k = 0; k < RT_GUIDE_K; k++) {
+               const int leaf = (int)guide[(1 + k) * RT_BLOCK];
+               const bool have = k < kept && leaf >= lo && leaf < hi;
+               in_l = in_l || (have && leaf < split); in_r = in_r || (have && leaf >= split);
+            }
+            l = in_l ? l : inf; r = in_r ? r : inf;
+         }
+      }
       const float cut = look_cut();
       bool goR = r <= l && r < cut;
       bool goL = !goR && l < cut;
@@ -636,7 +680,10 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
       if (TWO && (sc.filter_kinds & kind_bit) && c.fast && !wave_lit && !(c.par & RT_PAR_NO_FILTER)) {
          cur = sc.filter_root; mode |= MODE_FILTER;
          if (OUT == OUT_CHAIN) {
-            if ((mode & MODE_KIND) == MODE_EXTEND) toBeat = FLT_MAX;      /* the nearest of the other primitives, so far */
+            if ((mode & MODE_KIND) == MODE_EXTEND) {
+               toBeat = FLT_MAX;      /* the nearest of the other primitives, so far */
+               guide[0] = 0u; guide[(RT_GUIDE_K + 1) * RT_BLOCK] = __float_as_uint(-FLT_MAX);
+            }
             else t = toBeat * (1.0f + RT_FEELER_REL) + slack;             /* nothing that starts behind the target can shadow it */
          }
       } else cur = sc.root;
@@ -781,6 +828,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
       unsigned long long m_active = __ballot(active);
       int n_idle = 64 - __popcll(m_active);
       bool any_pend = OUT == OUT_CHAIN && __ballot(pend) != 0;
+      /* A wave that holds a ray long under way is issued ahead of the other waves of its SIMD.  The launch ends with the
+       * longest chains of dependent steps (a contested primary, then a feeler that walks the reference's tree in full);
+       * each of their steps waits for its wave to come round again, and while the chip is full that takes several times
+       * the memory latency.  Scheduling only: no result depends on it. */
+      if (__ballot(active && born > RT_OLD_RAY) != 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
       if ((n_idle >= refill_idle || m_active == 0) && (!exhausted || list_count > 0 || any_pend)) {
          const unsigned long long clk0 = COUNT ? wall_clock64() : 0ULL;
          if (COUNT) n_refills++;
@@ -959,6 +1011,9 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
       auto burst_loop = [&](auto variant_tag) {
          /* no ray enters the second tree during a burst (that happens in refills and leaf steps) */
          burst_filter = TWO && __ballot(active && (mode & MODE_FILTER)) != 0;
+         /* (a ray that turns to a guided walk during the burst walks unguided until the next one: the same walk, with
+          * visits that change nothing) */
+         burst_guided = TWO && OUT == OUT_CHAIN && __ballot(active && (mode & MODE_GUIDED)) != 0;
 #pragma unroll 1
          for (int burst = 0; burst < node_burst; burst++) {
             bool in_node = cur >= 0;                 /* idle lanes hold RT_CUR_IDLE */
@@ -1011,6 +1066,13 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
                   /* a closest-hit ray keeps the nearest primitive it meets (t, closest) and the parameter of the
                    * nearest of the others (toBeat) */
                   if (above_zero(dist)) {
+                     /* (what a guided walk would keep: everything met within the range that is searched completely) */
+                     if (dist < look_cut()) {
+                        const unsigned kept = guide[0];
+                        if (kept < RT_GUIDE_K) guide[(1 + kept) * RT_BLOCK] = (unsigned)~cur;
+                        guide[0] = kept + 1u;
+                        guide[(RT_GUIDE_K + 1) * RT_BLOCK] = __float_as_uint(fmaxf(__uint_as_float(guide[(RT_GUIDE_K + 1) * RT_BLOCK]), dist));
+                     }
                      if (dist < t) { toBeat = t; t = dist; closest = ~cur; }
                      else toBeat = fminf(toBeat, dist);
                   }
@@ -1130,7 +1192,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
       if (lane == 0 && blockIdx.x == 7 && threadIdx.x == 0) printf("refill ticks: total %llu, before the counter %llu, waiting for it %llu, slot known at %llu, ray made at %llu, refills %u\n", clk_refill, dbg_pre, dbg_wait, dbg_c, dbg_d, n_refills);
 #endif
       stat_add(stats, ST_CERT_OK, (unsigned long long)n_cert); stat_add(stats, ST_CERT_RIVAL, (unsigned long long)n_rival);
-      stat_add(stats, ST_CERT_UNREACHED, (unsigned long long)n_unreached);
+      stat_add(stats, ST_CERT_UNREACHED, (unsigned long long)n_unreached); stat_add(stats, ST_GUIDED, (unsigned long long)n_guided);
       stat_add(stats, ST_SHADOW_CERT, (unsigned long long)n_shadow_cert);
       stat_add(stats, ST_LEAF_WAIT, (unsigned long long)n_leafwait);
       stat_add(stats, ST_NO_RAY, (unsigned long long)n_noray);

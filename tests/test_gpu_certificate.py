@@ -94,10 +94,60 @@ def layered(offsets, n=60, seed=3, glass=False):
 def test_layers_around_the_tie_window(offsets):
     st = both_ways(layered(offsets), 240, 160, 1)
     assert st["hits_certified"] + st["hits_contested"] + st["hits_unreached"] > 0
+    assert st["hits_guided"] <= st["hits_contested"]
     if min(abs(o) for o in offsets) < 0.009:
-        assert st["hits_contested"] > 0          # rivals within the window: the reference's walk has to be made
+        assert st["hits_contested"] > 0          # rivals within the window: the reference's walk has to be made,
+        assert st["hits_guided"] > 0             # but only where the few primitives near the hit are
     else:
         assert st["hits_certified"] > 0
+
+
+# ---- contested hits: the guided walk -----------------------------------------------------------------------------------
+# A ray with rivals within the tie window walks the reference's tree, but only the subtrees that hold one of the primitives
+# it met in the second tree -- if those are few (four at most) and all within 0.03 of the nearest, while everything else is
+# known to be 0.045 or more behind it.  The layers below sit on both sides of each of those limits.
+@pytest.mark.parametrize("offsets", [(0.002, 0.004, 0.006), (0.002, 0.004, 0.006, 0.008), (0.001, 0.002, 0.003, 0.004, 0.005, 0.006),
+                                     (0.004, 0.029), (0.004, 0.031), (0.004, 0.0295, 0.0305, 0.044, 0.046), (0.009, 0.018, 0.027, 0.036, 0.045, 0.054),
+                                     (0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 0.0, 0.0)])
+def test_layers_around_the_limits_of_the_guided_walk(offsets):
+    st = both_ways(layered(offsets, n=50, seed=11), 240, 160, 1)
+    assert st["hits_contested"] > 0 and st["hits_guided"] <= st["hits_contested"]
+    if len(offsets) <= 3 and max(offsets) < 0.028:
+        assert st["hits_guided"] > 0
+    if len(offsets) >= 5 and max(offsets) < 0.01:
+        assert st["hits_guided"] < st["hits_contested"]        # more rivals than a ray keeps: the walk in full
+
+
+def test_guided_walk_on_a_mesh_seen_at_its_vertices():
+    """A height field looked at without jitter from straight above its middle: rays through vertices and along edges meet
+    up to six triangles at one parameter."""
+    sd = synth.terrain(24, 12, lights_per_side=1)
+    sd.camera = {"pos": np.array([0.0, 30.0, 0.0], np.float32), "up": np.array([0, 0, 1], np.float32),
+                 "right": np.array([1.3333, 0, 0], np.float32), "look_at": np.array([0.0, 0.0, 0.0], np.float32)}
+    got = []
+    for use in (True, False):
+        with ra.Scene(sd, miss_filter=use, counters=True) as sc:
+            frame, st = sc.render(193, 145, 1, abi.RT_PHONG, abi.RT_JITTER_NONE, 0)
+            prim, t = sc.trace_primary(193, 145, 1, abi.RT_JITTER_NONE, 0)
+            got.append((frame, prim, t, st))
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2].view(np.uint32), got[1][2].view(np.uint32))
+    assert got[0][0].tobytes() == got[1][0].tobytes()
+    osc = orclib.OracleScene(sd)
+    try:
+        r = osc.render(193, 145, 1, abi.RT_PHONG, abi.RT_JITTER_NONE, 0, 0, 4, want_samples=False, want_primary=True)
+    finally:
+        osc.close()
+    assert np.array_equal(r["prim"], got[0][1]) and np.array_equal(r["t"].view(np.uint32), got[0][2].view(np.uint32))
+
+
+def test_no_guided_walk_from_inside_the_tree():
+    """A ray that starts inside the box of the reference's root may start inside boxes further down; their values are then
+    exit distances and the argument for leaving subtrees out does not hold: such rays make the walk in full."""
+    sd = layered((0.004, 0.006), n=50, seed=5)
+    sd.camera["pos"] = np.array([0.0, 0.0, 0.3], np.float32)
+    sd.camera["look_at"] = np.array([0.0, 0.0, -1.0], np.float32)
+    st = both_ways(sd, 200, 150, 1)
+    assert st["hits_guided"] == 0
 
 
 def test_layers_with_mirrors_and_glass():
