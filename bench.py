@@ -231,8 +231,40 @@ def counted_shape(ct):
             "lane_utilisation_node_steps": round(nv / max(1, 64 * ct["wave_node_steps"]), 3),
             "lane_utilisation_leaf_steps": round(npt / max(1, 64 * ct["wave_leaf_steps"]), 3),
             "wave_time_refill": round(ct["wave_time_refill"], 3), "wave_time_node": round(ct["wave_time_node"], 3), "wave_time_leaf": round(ct["wave_time_leaf"], 3),
-            "hits_certified": ct["hits_certified"], "hits_contested": ct["hits_contested"], "hits_unreached": ct["hits_unreached"],
+            "hits_certified": ct["hits_certified"], "hits_contested": ct["hits_contested"], "hits_guided": ct["hits_guided"], "hits_unreached": ct["hits_unreached"],
             "shadows_certified": ct["shadows_certified"], "second_tree": ct["second_tree"]}
+
+
+def terrain_roofline(s4, c4, gbs, fetched, info):
+    """The roofline object of the 1M-triangle scene's 1080p x 4 spp frame.  Which level serves the record fetches is read
+    from the committed counter passes of that frame (profiles/<tag>_terrain_traffic.json): the ceiling is the one of the
+    level that serves most of them."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_terrain_traffic.json")
+    t = json.load(open(path)) if os.path.exists(path) else {}
+    hit_rate = t.get("l2_hit_rate")
+    launch_s = s4["ms_trace"] / max(1, s4["launches_trace"]) * 1e-3
+    from_l2 = t.get("l1_read_requests_to_l2_per_launch")
+    in_l2 = hit_rate is not None and hit_rate >= 0.8
+    peak = GATHER64_PEAK_GBS if in_l2 else MALL_GATHER_GBS
+    return {"frame": "the same scene at 1920x1080, 4 spp (%.0f ms per frame, %d rays)" % (s4["ms_total"], s4["rays_total"]),
+            "bound": "hbm", "level": "l2" if in_l2 else "infinity cache", "kernel": "k_trace<OUT_CHAIN> without the second tree",
+            "achieved": round(gbs, 1), "peak": peak, "unit": "GB/s", "frac": round(gbs / peak, 4),
+            "peak_from_the_infinity_cache": MALL_GATHER_GBS, "peak_beyond_the_cache": BIG_GATHER_GBS,
+            "bytes_per_launch": int(fetched), "avg_launch_ms": round(launch_s * 1e3, 3),
+            "ms_behind_trace": round(s4["ms_total"] - s4["ms_trace"], 3),
+            "ms_light_sums_counted_frame": round(c4["ms_light"], 3), "ms_resolve_counted_frame": round(c4["ms_resolve"], 3),
+            "traffic": t.get("hbm_bytes_per_launch"),
+            "served_by": {"l1_tag_requests_per_launch": t.get("l1_tag_requests_per_launch"), "l1_read_requests_to_l2_per_launch": from_l2,
+                          "l2_hit_rate": None if hit_rate is None else round(hit_rate, 4),
+                          "GBs_out_of_l2": None if from_l2 is None else round(from_l2 * 64 / launch_s / 1e9, 1),
+                          "GBs_fabric_side": None if t.get("hbm_bytes_per_launch") is None else round(t["hbm_bytes_per_launch"] / launch_s / 1e9, 1)},
+            "note": "`achieved` = 64 bytes per node and primitive record this kernel's walk fetched + 48 per ray (counted frame) / the launch duration of the "
+                    "uncounted one.  The scene's records (%.0f MB) do not fit the XCDs' L2, yet the counter passes of this frame (profiles/%s_terrain_*.json) "
+                    "show where the fetches are served: neighbouring lanes walk the same nodes, so the CUs' vector L1 merges them (a tag request is one "
+                    "128-byte line per instruction, however many lanes want it), L2 hits most of what is left, and `traffic` (fabric-side bytes per launch: "
+                    "FETCH_SIZE doubled + WRITE_SIZE) is a few percent of `bytes_per_launch`.  `peak` is therefore this part's ceiling for divergent 64-byte "
+                    "fetches out of L2 (profiles/microbench/gather64.hip); the guide's figures for random rows from the Infinity Cache and from beyond it are "
+                    "beside it.  Like the headline, the launch is bound by its waves' dependent chains, not by bytes." % (info["device_bytes"] / 1e6, PROFILE_TAG)}
 
 
 def secondary_frames(ra, abi, torch, stream):
@@ -287,6 +319,11 @@ def secondary_frames(ra, abi, torch, stream):
             s4 = best_of(sc, p4, buf.data_ptr(), stream, 2)
         with ra.Scene(big, device=0, fast_bvh=True, counters=True) as sc:
             c4 = sc.render_device(p4, buf.data_ptr(), stream)
+        # the tree built on the device instead (Morton codes + radix tree): what the quicker build costs per frame
+        with ra.Scene(big, device=0, gpu_bvh=True) as sc:
+            info_g = sc.info()
+            sc.render_device(p4, buf.data_ptr(), stream)
+            g4 = best_of(sc, p4, buf.data_ptr(), stream, 2)
         be, bs = algorithmic_bytes(c4)
         fetched = (be + bs) / max(1, c4["launches_trace"])
         gbs = (be + bs) / (s4["ms_trace"] * 1e-3) / 1e9
@@ -295,18 +332,11 @@ def secondary_frames(ra, abi, torch, stream):
             "Mrays_per_s": round(st["rays_total"] / st["ms_total"] / 1e3, 1), "rays_per_frame": st["rays_total"],
             "launches_per_frame": st["launches_trace"], "host_tree_build_ms": round(info["ms_build_host"], 0), "scene_generation_s": round(t_gen, 2),
             "scene_bytes": int(info["device_bytes"]),
-            "roofline": dict({"frame": "the same scene at 1920x1080, 4 spp (%.0f ms per frame, %d rays)" % (s4["ms_total"], s4["rays_total"]),
-                              "bound": "hbm", "level": "infinity cache", "kernel": "k_trace<OUT_CHAIN> without the second tree",
-                              "achieved": round(gbs, 1), "peak": MALL_GATHER_GBS, "unit": "GB/s", "frac": round(gbs / MALL_GATHER_GBS, 4),
-                              "peak_beyond_the_cache": BIG_GATHER_GBS, "bytes_per_launch": int(fetched), "avg_launch_ms": round(s4["ms_trace"] / max(1, s4["launches_trace"]), 3),
-                              "ms_behind_trace": round(s4["ms_total"] - s4["ms_trace"], 3),
-                              "ms_light_sums_counted_frame": round(c4["ms_light"], 3), "ms_resolve_counted_frame": round(c4["ms_resolve"], 3),
-                              "traffic": (json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_terrain_traffic.json"))).get("hbm_bytes_per_launch")
-                                          if os.path.exists(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_terrain_traffic.json")) else None),
-                              "note": "`achieved` = 64 bytes per node and primitive record this kernel's walk fetched + 48 per ray (counted frame) / the launch "
-                                      "duration of the uncounted one; the scene's records (%.0f MB) are past the XCDs' L2 and inside the 256 MiB Infinity Cache, "
-                                      "so `peak` is the guide's figure for uniformly random rows served from there (8.6 TB/s; 7.4-7.9 TB/s beyond it); `traffic` = "
-                                      "fabric-side bytes per launch from profiles/%s_terrain_traffic.json" % (info["device_bytes"] / 1e6, PROFILE_TAG)},
+            "device_built_tree": {"build_ms_host_side": round(info_g["ms_build_host"], 1), "build_ms_device_kernels": round(info_g["ms_build_device"], 2),
+                                  "frame_ms_1080p_4spp": round(g4["ms_total"], 1), "frame_ms_1080p_4spp_surface_area_tree": round(s4["ms_total"], 1),
+                                  "note": "RT_SCENE_GPU_BVH: the build drops from the host's %.0f ms to this; the frame costs the ratio of the two frame times "
+                                          "more, so the host's surface-area tree pays for itself after a few frames of this size" % info["ms_build_host"]},
+            "roofline": dict(terrain_roofline(s4, c4, gbs, fetched, info),
                              **counted_shape(c4)),
             "wall_s_incl_scene_generation_and_build": round(time.perf_counter() - t0, 1)}
     except Exception as e:      # reported, not hidden: the headline above does not depend on this frame
@@ -396,7 +426,21 @@ def end_to_end(ra, abi, first_ms, steady_ms):
         t0 = time.perf_counter()
         ra.launch_kernel(sd, ra.PHONG, 800, 600, frame, 1)
         dt = time.perf_counter() - t0
+        # the same call taken apart (a second scene of the same file: the library and the device are warm by now, as they
+        # are for the call above after the headline frames)
+        t1 = time.perf_counter()
+        sc = ra.Scene(sd)
+        t2 = time.perf_counter()
+        info = sc.info()
+        _, st = sc.render(800, 600, 1, ra.PHONG, abi.RT_JITTER_HASH)
+        t3 = time.perf_counter()
+        sc.close()
+        t4 = time.perf_counter()
         out["cold_call_800x600"][name] = {"wall_ms": round(dt * 1e3, 2),
+                                          "parts_ms": {"scene_create": round((t2 - t1) * 1e3, 2), "of_it_host_tree_builds": round(info["ms_build_host"], 2),
+                                                       "of_it_upload_and_allocations": round(info["ms_upload"], 2),
+                                                       "first_frame_call_with_copy_back": round((t3 - t2) * 1e3, 2), "of_it_on_the_device": round(st["ms_total"], 3),
+                                                       "scene_destroy": round((t4 - t3) * 1e3, 2)},
                                           "reference_whole_program_s": README_WALL_S[name],
                                           "note": "reference figure: `time ./raytrace` incl. parse + TGA on an unnamed sm_20 GPU (README:30-40); context, not a like-for-like baseline"}
     return out

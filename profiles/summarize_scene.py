@@ -52,9 +52,16 @@ def main():
     if best:
         k, v = best
         fetch, write = v["FETCH_SIZE"]["last_launch"], v.get("WRITE_SIZE", {}).get("last_launch", 0.0)
+        last = lambda c: v.get(c, {}).get("last_launch")
+        hit, miss = last("TCC_HIT_sum"), last("TCC_MISS_sum")
+        tags = [last("TCP_TAGRAM%d_REQ_sum" % i) for i in range(4)]
         json.dump({"kernel": k, "tag": tag, "frame": name, "fetch_size_kib_last_launch_raw": fetch, "write_size_kib_last_launch_raw": write,
                    "correction": "FETCH_SIZE x2 (gfx950 tallies 128-byte requests as 64 bytes); WRITE_SIZE as reported",
-                   "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024)},
+                   "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024),
+                   "launch_ns_under_the_kernel_trace": v["kernel_trace"]["last_launch_ns"],
+                   "l2_hits_per_launch": hit, "l2_misses_per_launch": miss, "l2_hit_rate": (hit / (hit + miss) if hit is not None and miss is not None and hit + miss > 0 else None),
+                   "l1_read_requests_to_l2_per_launch": last("TCP_TCC_READ_REQ_sum"),
+                   "l1_tag_requests_per_launch": (sum(tags) if all(t is not None for t in tags) else None)},
                   open(os.path.join(ROOT, "profiles", f"{tag}_{name}_traffic.json"), "w"), indent=1)
     for k, v in out["kernels"].items():
         print(k, {c: round(x.get("last_launch", x.get("last_launch_ns", 0))) for c, x in v.items()})

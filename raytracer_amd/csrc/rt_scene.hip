@@ -212,10 +212,21 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    if (e != hipSuccess) { rt_set_error("hipMalloc(%zu) failed: %s", s->dev_bytes, hipGetErrorString(e)); rt_scene_destroy(s); return RT_ERR_HIP; }
    const void *src[N_ARR] = {d_nodes.data(), d_prims.data(), d_xforms.data(), d_shades.data(), h.planes, h.materials, h.lights, h.tex_info,
                              h.texels, ids.data(), leaf_parent.data()};
-   for (int k = 0; k < N_ARR; k++) {
-      if (!sizes[k]) continue;
-      e = hipMemcpy((char *)s->dev_blob + off[k], src[k], sizes[k], hipMemcpyHostToDevice);
-      if (e != hipSuccess) { rt_set_error("scene upload failed: %s", hipGetErrorString(e)); rt_scene_destroy(s); return RT_ERR_HIP; }
+   {
+      /* one copy for all of it: a scene of a few megabytes spends more on the eleven calls than on the bytes (a scene
+       * of hundreds of megabytes is not staged a second time on the host: its arrays go one by one) */
+      const bool staged = s->dev_bytes <= ((size_t)64 << 20);
+      std::vector<char> stage(staged ? s->dev_bytes : 0);
+      for (int k = 0; k < N_ARR; k++) {
+         if (!sizes[k]) continue;
+         if (staged) { memcpy(stage.data() + off[k], src[k], sizes[k]); continue; }
+         e = hipMemcpy((char *)s->dev_blob + off[k], src[k], sizes[k], hipMemcpyHostToDevice);
+         if (e != hipSuccess) { rt_set_error("scene upload failed: %s", hipGetErrorString(e)); rt_scene_destroy(s); return RT_ERR_HIP; }
+      }
+      if (staged) {
+         e = hipMemcpy(s->dev_blob, stage.data(), s->dev_bytes, hipMemcpyHostToDevice);
+         if (e != hipSuccess) { rt_set_error("scene upload failed: %s", hipGetErrorString(e)); rt_scene_destroy(s); return RT_ERR_HIP; }
+      }
    }
    char *b = (char *)s->dev_blob;
    s->d.nodes = (const rt_bvh_node *)(b + off[0]); s->d.prims = (const rt_dev_prim *)(b + off[1]);
