@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <algorithm>
 #include <new>
@@ -103,65 +104,97 @@ void fill_xform(rt_dev_xform *x, const float *inv)
       for (int c = 0; c < 4; c++) x->r[k][c] = inv[c * 4 + k];
 }
 
+/* a material as a key: its bytes (a scene may give every primitive a material of its own: a million keys) */
 struct MatKey {
    rt_material m;
-   bool operator<(const MatKey &o) const { return memcmp(&m, &o.m, sizeof m) < 0; }
+   bool operator==(const MatKey &o) const { return memcmp(&m, &o.m, sizeof m) == 0; }
+};
+struct MatKeyHash {
+   size_t operator()(const MatKey &k) const
+   {
+      uint64_t h = 0xcbf29ce484222325ULL;
+      uint32_t w[(sizeof(rt_material) + 3) / 4] = {0};
+      memcpy(w, &k.m, sizeof k.m);
+      for (uint32_t v : w) { h ^= v; h *= 0x100000001b3ULL; h ^= h >> 29; }
+      return (size_t)h;
+   }
 };
 
-struct Builder {
-   std::vector<rt_dev_prim> prims;
-   std::vector<rt_dev_xform> xforms;
-   std::vector<rt_dev_shade> shades;
-   std::vector<Box3> boxes;       /* getBoundingBox() per primitive */
-   std::vector<F3> centers;       /* getCenter() per primitive: the sort key */
+/* the deduplicated materials, in order of first appearance */
+struct MatTable {
    std::vector<rt_material> materials;
-   std::map<MatKey, uint32_t> mat_index;
-   int any_xform = 0;
-
-   uint32_t material(const rt_material &m)
+   std::unordered_map<MatKey, uint32_t, MatKeyHash> index;
+   uint32_t id_of(const rt_material &m)
    {
       MatKey k; memset(&k, 0, sizeof k); k.m = m;
-      auto it = mat_index.find(k);
-      if (it != mat_index.end()) return it->second;
+      auto it = index.find(k);
+      if (it != index.end()) return it->second;
       uint32_t id = (uint32_t)materials.size();
       materials.push_back(m);
-      mat_index[k] = id;
+      index[k] = id;
       return id;
    }
+};
 
-   void common(rt_dev_prim &p, uint32_t type, const rt_modifier &mod)
+/* The per-primitive records, written by index (several threads fill disjoint ranges of a large scene: a million
+ * records are a gigabyte of host memory touched for the first time, which one thread does no faster than the memory
+ * is mapped for it).  prims, xforms and shades are handed to the caller as they are. */
+struct Builder {
+   rt_dev_prim *prims = nullptr;
+   rt_dev_xform *xforms = nullptr;
+   rt_dev_shade *shades = nullptr;
+   std::vector<Box3> boxes;       /* getBoundingBox() per primitive */
+   std::vector<F3> centers;       /* getCenter() per primitive: the sort key */
+   MatTable mats;                 /* the scene's table: the planes' materials first, then the primitives' */
+
+   ~Builder() { free(prims); free(xforms); free(shades); }
+   bool allocate(size_t n)
    {
+      const size_t m = n ? n : 1;
+      prims = (rt_dev_prim *)malloc(m * sizeof(rt_dev_prim));
+      xforms = (rt_dev_xform *)malloc(m * sizeof(rt_dev_xform));
+      shades = (rt_dev_shade *)malloc(m * sizeof(rt_dev_shade));
+      if (!prims || !xforms || !shades) return false;
+      boxes.resize(n); centers.resize(n);
+      return true;
+   }
+
+   /* (the material number is the filling thread's own until the tables are merged) */
+   void common(size_t at, uint32_t type, const rt_modifier &mod, MatTable &mt, int &any_xform)
+   {
+      rt_dev_prim &p = prims[at];
       memset(&p, 0, sizeof p);
       p.type = type;
-      p.material = material(mod.mat);
+      p.material = mt.id_of(mod.mat);
       if (!is_identity(mod.inv_trans)) { p.flags |= RT_FLAG_XFORM; any_xform = 1; }
-      rt_dev_xform x; fill_xform(&x, mod.inv_trans);
-      xforms.push_back(x);
+      fill_xform(&xforms[at], mod.inv_trans);
    }
 
    /* Sphere.h:10-15, 26-32 */
-   void add_sphere(const rt_sphere &s)
+   void add_sphere(size_t at, const rt_sphere &s, MatTable &mt, int &any_xform)
    {
-      rt_dev_prim p; common(p, RT_PRIM_SPHERE, s.mod);
+      common(at, RT_PRIM_SPHERE, s.mod, mt, any_xform);
+      rt_dev_prim &p = prims[at];
       p.g[0] = s.c[0]; p.g[1] = s.c[1]; p.g[2] = s.c[2]; p.g[3] = s.r;
-      rt_dev_shade sh; memset(&sh, 0, sizeof sh);
+      rt_dev_shade &sh = shades[at]; memset(&sh, 0, sizeof sh);
       F3 wc = mat_vec(s.mod.trans, s.c[0], s.c[1], s.c[2], 1.0f);
       put(sh.s, wc);
-      prims.push_back(p); shades.push_back(sh);
-      centers.push_back(wc);
-      boxes.push_back(corners_box(F3{s.c[0] - s.r, s.c[1] - s.r, s.c[2] - s.r},
-                                  F3{s.c[0] + s.r, s.c[1] + s.r, s.c[2] + s.r}, s.mod.trans));
+      centers[at] = wc;
+      boxes[at] = corners_box(F3{s.c[0] - s.r, s.c[1] - s.r, s.c[2] - s.r},
+                              F3{s.c[0] + s.r, s.c[1] + s.r, s.c[2] + s.r}, s.mod.trans);
    }
 
    /* Triangle.h:11-42; SmoothTriangle.h:12-28 */
-   void add_triangle(const float *a, const float *b, const float *c, const rt_modifier &mod,
-                     const float *n1, const float *n2, const float *n3, const float *vt1, const float *vt2, const float *vt3)
+   void add_triangle(size_t at, const float *a, const float *b, const float *c, const rt_modifier &mod,
+                     const float *n1, const float *n2, const float *n3, const float *vt1, const float *vt2, const float *vt3,
+                     MatTable &mt, int &any_xform)
    {
-      rt_dev_prim p; common(p, n1 ? RT_PRIM_SMOOTH : RT_PRIM_TRIANGLE, mod);
+      common(at, n1 ? RT_PRIM_SMOOTH : RT_PRIM_TRIANGLE, mod, mt, any_xform);
+      rt_dev_prim &p = prims[at];
       F3 p1 = f3(a), p2 = f3(b), p3 = f3(c);
       F3 n = normalize(cross(p2 - p1, p3 - p1));
       put(&p.g[0], p1); put(&p.g[3], p2); put(&p.g[6], p3); put(&p.g[9], n);
-      rt_dev_shade sh; memset(&sh, 0, sizeof sh);
+      rt_dev_shade &sh = shades[at]; memset(&sh, 0, sizeof sh);
       if (n1) {
          put(&sh.s[0], vec_mat(n1[0], n1[1], n1[2], 0.0f, mod.inv_trans));
          put(&sh.s[3], vec_mat(n2[0], n2[1], n2[2], 0.0f, mod.inv_trans));
@@ -170,34 +203,33 @@ struct Builder {
          put(&sh.s[0], vec_mat(n.x, n.y, n.z, 0.0f, mod.inv_trans));
       }
       sh.s[9] = vt1[0]; sh.s[10] = vt1[1]; sh.s[11] = vt2[0]; sh.uv[0] = vt2[1]; sh.uv[1] = vt3[0]; sh.uv[2] = vt3[1];
-      prims.push_back(p); shades.push_back(sh);
       /* sort key: centroid as a ROW vector times trans -- the translation column never enters (Triangle.h:28-31) */
       F3 s3 = (p1 + p2) + p3;
       F3 cen = F3{s3.x / 3.0f, s3.y / 3.0f, s3.z / 3.0f};
-      centers.push_back(vec_mat(cen.x, cen.y, cen.z, 1.0f, mod.trans));
+      centers[at] = vec_mat(cen.x, cen.y, cen.z, 1.0f, mod.trans);
       F3 t1 = mat_vec(mod.trans, p1.x, p1.y, p1.z, 1.0f);
       F3 t2 = mat_vec(mod.trans, p2.x, p2.y, p2.z, 1.0f);
       F3 t3 = mat_vec(mod.trans, p3.x, p3.y, p3.z, 1.0f);
       F3 mn = F3{lo(lo(t1.x, t2.x), t3.x), lo(lo(t1.y, t2.y), t3.y), lo(lo(t1.z, t2.z), t3.z)};
       F3 mx = F3{hi(hi(t1.x, t2.x), t3.x), hi(hi(t1.y, t2.y), t3.y), hi(hi(t1.z, t2.z), t3.z)};
-      boxes.push_back(padded(mn, mx));
+      boxes[at] = padded(mn, mx);
    }
 
    /* Box.h:13-34 */
-   void add_box(const rt_box &b)
+   void add_box(size_t at, const rt_box &b, MatTable &mt, int &any_xform)
    {
-      rt_dev_prim p; common(p, RT_PRIM_BOX, b.mod);
+      common(at, RT_PRIM_BOX, b.mod, mt, any_xform);
+      rt_dev_prim &p = prims[at];
       F3 mn = F3{lo(b.p1[0], b.p2[0]), lo(b.p1[1], b.p2[1]), lo(b.p1[2], b.p2[2])};
       F3 mx = F3{hi(b.p1[0], b.p2[0]), hi(b.p1[1], b.p2[1]), hi(b.p1[2], b.p2[2])};
       put(&p.g[0], mn); put(&p.g[3], mx);
-      rt_dev_shade sh; memset(&sh, 0, sizeof sh);
+      rt_dev_shade &sh = shades[at]; memset(&sh, 0, sizeof sh);
       for (int c = 0; c < 3; c++)
          for (int r = 0; r < 3; r++) sh.s[c * 3 + r] = b.mod.trans[c * 4 + r];
-      prims.push_back(p); shades.push_back(sh);
       F3 s2 = mn + mx;
       F3 mid = F3{s2.x / 2.0f, s2.y / 2.0f, s2.z / 2.0f};
-      centers.push_back(mat_vec(b.mod.trans, mid.x, mid.y, mid.z, 1.0f));
-      boxes.push_back(corners_box(mn, mx, b.mod.trans));
+      centers[at] = mat_vec(b.mod.trans, mid.x, mid.y, mid.z, 1.0f);
+      boxes[at] = corners_box(mn, mx, b.mod.trans);
    }
 };
 
@@ -384,6 +416,12 @@ struct SahBuilder {
 };
 
 /* a material's texture reference must name a texture whose pixels are there */
+/* the same test without the message (what the filling threads use) */
+bool tex_known(const rt_scene_desc *d, int tex_id)
+{
+   return tex_id == -1 || !(tex_id < 0 || tex_id >= d->n_textures || !d->textures || !d->textures[tex_id].rgba ||
+                            d->textures[tex_id].width <= 0 || d->textures[tex_id].height <= 0);
+}
 bool tex_ok(const rt_scene_desc *d, int tex_id)
 {
    if (tex_id == -1) return true;
@@ -431,8 +469,7 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
    memset(out, 0, sizeof *out);
 
    Builder b;
-   b.prims.reserve((size_t)total); b.xforms.reserve((size_t)total); b.shades.reserve((size_t)total);
-   b.boxes.reserve((size_t)total); b.centers.reserve((size_t)total);
+   if (!b.allocate((size_t)total)) { rt_set_error("out of memory for %lld primitive records", total); return RT_ERR_BAD_ARGUMENT; }
 
    /* planes first, as initScene does (kernel.cu:411-416); they stay out of the tree */
    std::vector<rt_dev_plane> planes((size_t)d->n_planes);
@@ -445,26 +482,74 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
       fill_xform(&o.inv, p.mod.inv_trans);
       put(o.wsN, mat_vec(p.mod.trans, p.n[0], p.n[1], p.n[2], 0.0f));
       if (!is_identity(p.mod.inv_trans)) o.flags |= RT_FLAG_XFORM;
-      o.material = b.material(p.mod.mat);
+      o.material = b.mats.id_of(p.mod.mat);
    }
-   /* geomList order: spheres, triangles, boxes, smooth triangles (kernel.cu:419-456) */
-   for (int i = 0; i < d->n_spheres; i++) {
-      if (!tex_ok(d, d->spheres[i].mod.mat.tex_id)) return RT_ERR_BAD_ARGUMENT;
-      b.add_sphere(d->spheres[i]);
-   }
-   for (int i = 0; i < d->n_triangles; i++) {
-      const rt_triangle &t = d->triangles[i];
-      if (!tex_ok(d, t.mod.mat.tex_id)) return RT_ERR_BAD_ARGUMENT;
-      b.add_triangle(t.p1, t.p2, t.p3, t.mod, NULL, NULL, NULL, t.vt1, t.vt2, t.vt3);
-   }
-   for (int i = 0; i < d->n_boxes; i++) {
-      if (!tex_ok(d, d->boxes[i].mod.mat.tex_id)) return RT_ERR_BAD_ARGUMENT;
-      b.add_box(d->boxes[i]);
-   }
-   for (int i = 0; i < d->n_smooth_triangles; i++) {
-      const rt_smooth_triangle &t = d->smooth_triangles[i];
-      if (!tex_ok(d, t.mod.mat.tex_id)) return RT_ERR_BAD_ARGUMENT;
-      b.add_triangle(t.p1, t.p2, t.p3, t.mod, t.n1, t.n2, t.n3, t.vt1, t.vt2, t.vt3);
+   /* geomList order: spheres, triangles, boxes, smooth triangles (kernel.cu:419-456).  Ranges of that order are filled
+    * side by side; each range numbers its materials by first appearance within it, and the ranges' tables are merged in
+    * order afterwards, which gives the numbers one pass over everything would have given. */
+   int any_xform = 0;
+   {
+      const long long first_tri = d->n_spheres, first_box = first_tri + d->n_triangles, first_smooth = first_box + d->n_boxes;
+      /* -1: filled; otherwise the first primitive of the range whose texture reference is bad */
+      auto fill = [&](long long lo_i, long long hi_i, MatTable &mt, int &xf) -> long long {
+         for (long long g = lo_i; g < hi_i; g++) {
+            if (g < first_tri) {
+               const rt_sphere &sp = d->spheres[g];
+               if (!tex_known(d, sp.mod.mat.tex_id)) return g;
+               b.add_sphere((size_t)g, sp, mt, xf);
+            } else if (g < first_box) {
+               const rt_triangle &t = d->triangles[g - first_tri];
+               if (!tex_known(d, t.mod.mat.tex_id)) return g;
+               b.add_triangle((size_t)g, t.p1, t.p2, t.p3, t.mod, NULL, NULL, NULL, t.vt1, t.vt2, t.vt3, mt, xf);
+            } else if (g < first_smooth) {
+               const rt_box &bx = d->boxes[g - first_box];
+               if (!tex_known(d, bx.mod.mat.tex_id)) return g;
+               b.add_box((size_t)g, bx, mt, xf);
+            } else {
+               const rt_smooth_triangle &t = d->smooth_triangles[g - first_smooth];
+               if (!tex_known(d, t.mod.mat.tex_id)) return g;
+               b.add_triangle((size_t)g, t.p1, t.p2, t.p3, t.mod, t.n1, t.n2, t.n3, t.vt1, t.vt2, t.vt3, mt, xf);
+            }
+         }
+         return -1;
+      };
+      unsigned hw = std::thread::hardware_concurrency();
+      int parts = total >= 65536 ? (int)(hw > 8 ? 8 : (hw > 1 ? hw : 1)) : 1;
+      std::vector<MatTable> tables((size_t)parts);
+      std::vector<int> xf((size_t)parts, 0);
+      std::vector<long long> bad((size_t)parts, -1);
+      auto range_lo = [&](int k) { return total * k / parts; };
+      {
+         std::vector<std::thread> workers;
+         struct JoinAll { std::vector<std::thread> &w; ~JoinAll() { for (auto &t : w) if (t.joinable()) t.join(); } } join_all{workers};
+         for (int k = 1; k < parts; k++) {
+            try { workers.emplace_back([&, k]() { bad[(size_t)k] = fill(range_lo(k), range_lo(k + 1), tables[(size_t)k], xf[(size_t)k]); }); }
+            catch (...) { bad[(size_t)k] = fill(range_lo(k), range_lo(k + 1), tables[(size_t)k], xf[(size_t)k]); }      /* no thread to be had: here, then */
+         }
+         bad[0] = fill(range_lo(0), range_lo(1), tables[0], xf[0]);
+      }
+      for (int k = 0; k < parts; k++) {
+         if (bad[(size_t)k] >= 0) {
+            /* the same check again, for its message */
+            const long long g = bad[(size_t)k];
+            const int tex = g < first_tri ? d->spheres[g].mod.mat.tex_id : g < first_box ? d->triangles[g - first_tri].mod.mat.tex_id
+                          : g < first_smooth ? d->boxes[g - first_box].mod.mat.tex_id : d->smooth_triangles[g - first_smooth].mod.mat.tex_id;
+            (void)tex_ok(d, tex);
+            return RT_ERR_BAD_ARGUMENT;
+         }
+      }
+      {
+         size_t most = b.mats.materials.size();
+         for (int k = 0; k < parts; k++) most += tables[(size_t)k].materials.size();
+         b.mats.materials.reserve(most); b.mats.index.reserve(most);
+      }
+      for (int k = 0; k < parts; k++) {
+         const MatTable &mt = tables[(size_t)k];
+         std::vector<uint32_t> global(mt.materials.size());
+         for (size_t m = 0; m < mt.materials.size(); m++) global[m] = b.mats.id_of(mt.materials[m]);
+         for (long long g = range_lo(k); g < range_lo(k + 1); g++) b.prims[g].material = global[b.prims[g].material];
+         any_xform |= xf[(size_t)k];
+      }
    }
 
    int n = (int)total;
@@ -599,8 +684,8 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
    }
 
    out->n_prims = n; out->n_planes = d->n_planes; out->n_lights = d->n_lights;
-   out->n_nodes = (int32_t)flat.size(); out->n_materials = (int32_t)b.materials.size();
-   out->root = root; out->tree_depth = depth; out->any_xform = b.any_xform;
+   out->n_nodes = (int32_t)flat.size(); out->n_materials = (int32_t)b.mats.materials.size();
+   out->root = root; out->tree_depth = depth; out->any_xform = any_xform;
    out->bounds_in_range = 1;
    {
       /* per sphere: the smallest half-axis it has in the world is at least radius * sqrt(3) / |inv_trans| (Frobenius norm
@@ -633,11 +718,10 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
    out->n_filter_nodes = (int32_t)filter.size(); out->filter_depth = filter_depth;
    out->filter_nodes = copy_out(filter);
    out->nodes = copy_out(flat);
-   out->prims = copy_out(b.prims);
-   out->xforms = copy_out(b.xforms);
-   out->shades = copy_out(b.shades);
+   out->prims = b.prims; out->xforms = b.xforms; out->shades = b.shades;      /* handed over as they are */
+   b.prims = nullptr; b.xforms = nullptr; b.shades = nullptr;
    out->planes = copy_out(planes);
-   out->materials = copy_out(b.materials);
+   out->materials = copy_out(b.mats.materials);
    out->lights = copy_out(lights);
    order.resize((size_t)n);
    out->leaf_order = copy_out(order);
