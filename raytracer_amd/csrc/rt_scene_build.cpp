@@ -239,7 +239,50 @@ inline float axis_of(const F3 &v, int axis) { return axis == 0 ? v.x : axis == 1
  * bottom-up merge of bvh.cpp:106-171.  In a merge the LEFT run's head is taken
  * only when its key is strictly smaller, so equal keys come out right-run
  * first -- this is not std::stable_sort and must not be replaced by it. */
+void merge_sort_range_literal(int32_t *ids, int32_t *tmp, int n, const std::vector<F3> &centers, int axis);
+
+/* What that merge computes, for keys without a NaN among them: each run it has built is in order of (key ascending,
+ * place in the input descending) -- runs of one trivially, and a merge of a left and a right run that takes the right
+ * head on equal keys keeps it so, the right run holding the later places.  So the outcome is the input sorted by key
+ * with equal keys in reverse input order, whatever the run boundaries were, and a stable radix sort of the input fed
+ * back to front gives the same permutation.  (-0 and +0 are equal keys to `<`: both are keyed as +0.)  Long ranges are
+ * sorted that way -- the merge's passes with a dependent load per comparison were most of a scene's host build -- short
+ * ones and any range with a NaN key by the merge itself; tests/native/bvh_sort_equivalence.cpp runs both on random,
+ * heavily tied, signed-zero and infinite keys. */
 void merge_sort_range(int32_t *ids, int32_t *tmp, int n, const std::vector<F3> &centers, int axis)
+{
+   if (n >= 192) {
+      static thread_local std::vector<uint64_t> a, b;
+      a.resize((size_t)n); b.resize((size_t)n);
+      bool ok = true;
+      uint32_t all_or = 0, all_and = 0xffffffffu;
+      for (int i = 0; i < n && ok; i++) {
+         const int32_t id = ids[n - 1 - i];
+         const float k = axis_of(centers[(size_t)id], axis) + 0.0f;
+         ok = k == k;
+         uint32_t u; memcpy(&u, &k, 4);
+         u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);      /* unsigned order = float order */
+         all_or |= u; all_and &= u;
+         a[(size_t)i] = ((uint64_t)u << 32) | (uint32_t)id;
+      }
+      if (ok) {
+         uint64_t *src = a.data(), *dst = b.data();
+         for (int shift = 32; shift < 64; shift += 8) {
+            if ((((all_or ^ all_and) >> (shift - 32)) & 0xffu) == 0) continue;      /* every key has the same digit here */
+            size_t count[257] = {0};
+            for (int i = 0; i < n; i++) count[((src[i] >> shift) & 0xffu) + 1]++;
+            for (int d = 0; d < 256; d++) count[d + 1] += count[d];
+            for (int i = 0; i < n; i++) dst[count[(src[i] >> shift) & 0xffu]++] = src[i];
+            uint64_t *t = src; src = dst; dst = t;
+         }
+         for (int i = 0; i < n; i++) ids[i] = (int32_t)(uint32_t)src[i];
+         return;
+      }
+   }
+   merge_sort_range_literal(ids, tmp, n, centers, axis);
+}
+
+void merge_sort_range_literal(int32_t *ids, int32_t *tmp, int n, const std::vector<F3> &centers, int axis)
 {
    int32_t *src = ids, *dst = tmp;
    for (int width = 1; width < n; width *= 2) {

@@ -1,10 +1,12 @@
-"""CPU checks of the two arithmetic shortcuts the HIP traversal relies on (tests/native/*.c).
+"""CPU checks of the shortcuts that stand in for the reference's literal arithmetic (tests/native/*).
 
-Both programs compare the shortcut with the reference's literal arithmetic bit for bit:
+Each program compares the shortcut with the literal form bit for bit:
   exact_div_hard_cases.c  every operand pair whose quotient is close enough to a rounding boundary
                           for the 3-operation division to be able to misround (exhaustive)
   slab_short_form.c       the short box test against boxIntersect (GeometryUtil.h:9-51), randomised, with and
                           without axis-parallel direction components
+  bvh_sort_equivalence.cpp  the radix sort that stands in for formBVH's merge rounds (bvh.cpp:106-171) in the host
+                          tree build, against the merge itself: the same permutation on every input
 """
 import os
 import subprocess
@@ -41,3 +43,13 @@ def test_short_slab_form(tmp_path):
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     assert "bad=0" in out and "bitdiff(incl zero sign)=0" in out, out
     assert int(out.split("with_parallel_axis=")[1].split()[0]) > 1_000_000, out
+
+
+def test_bvh_sort_rounds_radix_equals_merge(tmp_path):
+    exe = tmp_path / "bvhsort"
+    root = os.path.dirname(HERE)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "raytracer_amd", "csrc"),
+                    os.path.join(HERE, "native", "bvh_sort_equivalence.cpp"), "-o", str(exe), "-lpthread"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert "bad=0" in out, out
+    assert int(out.split("tested=")[1].split()[0]) > 15_000 and int(out.split("with_ties=")[1].split()[0]) > 5_000, out
