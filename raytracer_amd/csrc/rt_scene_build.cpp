@@ -362,9 +362,16 @@ inline F3 box_center(const Box3 &b) { return F3{0.5f * (b.mn.x + b.mx.x), 0.5f *
 
 struct SahBuilder {
    const std::vector<Box3> &boxes;
+   const std::vector<F3> &cent;       /* box_center of every primitive's box */
    std::vector<int32_t> &ids;
    std::vector<TreeNode> &pool;
    enum { BINS = 16 };
+
+   static int bin_of(float c, float lo_c, float scale)
+   {
+      int k = (int)((c - lo_c) * scale);
+      return k >= BINS ? BINS - 1 : (k < 0 ? 0 : k);
+   }
 
    /* `par`: how many more levels hand their right half to another thread (large ranges only).  The halves work on
     * disjoint ranges of `ids` and on node pools of their own; the tree is the same whatever `par` is. */
@@ -372,45 +379,54 @@ struct SahBuilder {
    {
       int n = last - first;
       if (n == 1) { int p = ids[(size_t)first]; pool.push_back(TreeNode{-1, -1, p, boxes[(size_t)p]}); return (int)pool.size() - 1; }
-      Box3 cb; bool have = false;
-      for (int i = first; i < last; i++) {
-         F3 c = box_center(boxes[(size_t)ids[(size_t)i]]);
-         Box3 pt{c, c};
-         cb = have ? unite(cb, pt) : pt; have = true;
+      F3 cmn = cent[(size_t)ids[(size_t)first]], cmx = cmn;
+      for (int i = first + 1; i < last; i++) {
+         const F3 &c = cent[(size_t)ids[(size_t)i]];
+         cmn = F3{lo(cmn.x, c.x), lo(cmn.y, c.y), lo(cmn.z, c.z)}; cmx = F3{hi(cmx.x, c.x), hi(cmx.y, c.y), hi(cmx.z, c.z)};
       }
       int levels_needed = 0; while ((1 << levels_needed) < n) levels_needed++;
       int mid = -1;
-      if (depth_left > levels_needed) {
+      /* (a handful of primitives is split at the median: the bins would say little more and most nodes are down here) */
+      if (depth_left > levels_needed && n > 4) {
+         /* one pass over the range fills the bins of all three axes */
+         const float lo3[3] = {cmn.x, cmn.y, cmn.z}, ext3[3] = {cmx.x - cmn.x, cmx.y - cmn.y, cmx.z - cmn.z};
+         float scale3[3];
+         for (int a = 0; a < 3; a++) scale3[a] = ext3[a] > 0.0f ? (float)BINS / ext3[a] : 0.0f;
+         const Box3 none{F3{FLT_MAX, FLT_MAX, FLT_MAX}, F3{-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+         Box3 bb[3][BINS]; int cnt[3][BINS];
+         for (int a = 0; a < 3; a++) for (int k = 0; k < BINS; k++) { bb[a][k] = none; cnt[a][k] = 0; }
+         for (int i = first; i < last; i++) {
+            const int32_t p = ids[(size_t)i];
+            const Box3 &pb = boxes[(size_t)p];
+            const F3 &c = cent[(size_t)p];
+            const float c3[3] = {c.x, c.y, c.z};
+            for (int a = 0; a < 3; a++) {
+               const int k = bin_of(c3[a], lo3[a], scale3[a]);
+               bb[a][k] = unite(bb[a][k], pb); cnt[a][k]++;
+            }
+         }
          float best = FLT_MAX; int best_axis = -1, best_bin = -1;
          for (int axis = 0; axis < 3; axis++) {
-            float lo_c = axis_of(cb.mn, axis), ext = axis_of(cb.mx, axis) - lo_c;
-            if (!(ext > 0.0f)) continue;
-            Box3 bb[BINS]; int cnt[BINS]; bool used[BINS];
-            for (int k = 0; k < BINS; k++) { cnt[k] = 0; used[k] = false; }
-            for (int i = first; i < last; i++) {
-               const Box3 &pb = boxes[(size_t)ids[(size_t)i]];
-               int k = (int)((axis_of(box_center(pb), axis) - lo_c) / ext * BINS); if (k >= BINS) k = BINS - 1; if (k < 0) k = 0;
-               bb[k] = used[k] ? unite(bb[k], pb) : pb; used[k] = true; cnt[k]++;
-            }
+            if (!(ext3[axis] > 0.0f) || !(scale3[axis] < FLT_MAX)) continue;
             float right_area[BINS]; int right_cnt[BINS];
-            Box3 acc; bool ha = false; int c = 0;
+            Box3 acc = none; int c = 0;
             for (int k = BINS - 1; k > 0; k--) {
-               if (used[k]) { acc = ha ? unite(acc, bb[k]) : bb[k]; ha = true; c += cnt[k]; }
-               right_area[k] = ha ? half_area(acc) : 0.0f; right_cnt[k] = c;
+               if (cnt[axis][k]) { acc = unite(acc, bb[axis][k]); c += cnt[axis][k]; }
+               right_area[k] = c ? half_area(acc) : 0.0f; right_cnt[k] = c;
             }
-            ha = false; c = 0;
+            acc = none; c = 0;
             for (int k = 0; k < BINS - 1; k++) {
-               if (used[k]) { acc = ha ? unite(acc, bb[k]) : bb[k]; ha = true; c += cnt[k]; }
+               if (cnt[axis][k]) { acc = unite(acc, bb[axis][k]); c += cnt[axis][k]; }
                if (c == 0 || right_cnt[k + 1] == 0) continue;
                float cost = half_area(acc) * (float)c + right_area[k + 1] * (float)right_cnt[k + 1];
                if (cost < best) { best = cost; best_axis = axis; best_bin = k; }
             }
          }
          if (best_axis >= 0) {
-            float lo_c = axis_of(cb.mn, best_axis), ext = axis_of(cb.mx, best_axis) - lo_c;
+            const float lo_c = lo3[best_axis], scale = scale3[best_axis];
             int i = first, j = last - 1;
             while (i <= j) {
-               int k = (int)((axis_of(box_center(boxes[(size_t)ids[(size_t)i]]), best_axis) - lo_c) / ext * BINS); if (k >= BINS) k = BINS - 1; if (k < 0) k = 0;
+               const int k = bin_of(axis_of(cent[(size_t)ids[(size_t)i]], best_axis), lo_c, scale);
                if (k <= best_bin) i++; else { std::swap(ids[(size_t)i], ids[(size_t)j]); j--; }
             }
             if (i > first && i < last) mid = i;
@@ -419,11 +435,11 @@ struct SahBuilder {
       if (mid < 0) {
          /* median split on the widest centroid axis (also the forced choice once the depth budget is tight) */
          int axis = 0;
-         float ex = cb.mx.x - cb.mn.x, ey = cb.mx.y - cb.mn.y, ez = cb.mx.z - cb.mn.z;
+         float ex = cmx.x - cmn.x, ey = cmx.y - cmn.y, ez = cmx.z - cmn.z;
          if (ey > ex && ey >= ez) axis = 1; else if (ez > ex && ez > ey) axis = 2;
          mid = first + n / 2;
          std::nth_element(ids.begin() + first, ids.begin() + mid, ids.begin() + last, [&](int32_t a, int32_t b) {
-            float ca = axis_of(box_center(boxes[(size_t)a]), axis), cb2 = axis_of(box_center(boxes[(size_t)b]), axis);
+            float ca = axis_of(cent[(size_t)a], axis), cb2 = axis_of(cent[(size_t)b], axis);
             return ca < cb2 || (ca == cb2 && a < b);
          });
       }
@@ -431,7 +447,7 @@ struct SahBuilder {
       if (par > 0 && n >= 2048) {
          std::vector<TreeNode> other_pool;
          other_pool.reserve((size_t)(2 * (last - mid)));
-         SahBuilder other{boxes, ids, other_pool};
+         SahBuilder other{boxes, cent, ids, other_pool};
          int r_local = -1;
          bool threaded = true;
          std::thread worker;
@@ -604,6 +620,12 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
     * reference's walk returns (no primitive met; or this one primitive, with no rival near it), and walks the reference's
     * tree for every ray it cannot prove that for.  Built only beside the reference's tree, and on a thread of its own
     * while that one is built here: the two read the same boxes and share nothing else. */
+   /* (the centres of the primitives' boxes, for the surface-area builder: both of its uses read them) */
+   std::vector<F3> box_centers;
+   if (n > 0 && (flags & RT_SCENE_FAST_BVH || !(flags & (RT_SCENE_GPU_BVH | RT_SCENE_NO_FILTER)))) {
+      box_centers.resize((size_t)n);
+      for (int i = 0; i < n; i++) box_centers[(size_t)i] = box_center(b.boxes[(size_t)i]);
+   }
    std::vector<rt_bvh_node> filter;
    int filter_depth = 0;
    int filter_min = RT_FILTER_MIN_PRIMS;
@@ -616,7 +638,7 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
       std::vector<TreeNode> pool;
       pool.reserve((size_t)(2 * n));
       int levels = 0; while ((1 << levels) < n) levels++;
-      SahBuilder sb{b.boxes, ids, pool};
+      SahBuilder sb{b.boxes, box_centers, ids, pool};
       /* no deeper than the traversal stack's share of LDS where the primitive count allows that: a tree that pushed
        * the stack into global memory would cost more than its better splits win */
       int budget = levels + 2 > RT_FILTER_DEPTH ? levels + 2 : RT_FILTER_DEPTH;
@@ -653,7 +675,7 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
       std::vector<TreeNode> pool;
       pool.reserve((size_t)(2 * n));
       int levels = 0; while ((1 << levels) < n) levels++;
-      SahBuilder sb{b.boxes, order, pool};
+      SahBuilder sb{b.boxes, box_centers, order, pool};
       int root_node = sb.build(0, n, levels + 8, 3);
       if (pool[(size_t)root_node].prim >= 0) root = ~pool[(size_t)root_node].prim;
       else { flatten_tree(pool, root_node, flat, &depth); root = 0; }
