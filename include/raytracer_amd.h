@@ -254,6 +254,12 @@ const char *rt_last_error(void);
  * 64-byte records and uploaded.  Replaces allocateGPUScene + formBVH
  * (kernel.cu:572-687, 732-733). */
 int rt_scene_create(const rt_scene_desc *desc, int device, int flags, rt_scene **out);
+/* A replica of `scene` on `device` (the same device is allowed): the host side -- flattened records, both trees -- is
+ * shared with the original and built only once, everything on the device is made anew.  The replicas of the device-list
+ * and frames-in-flight drivers are made this way.  A replica is an independent scene object: it renders the same bytes,
+ * keeps its own camera, tuning state and statistics, and either may be destroyed first.  No counterpart in the reference,
+ * which builds its one scene per call (kernel.cu:732-733). */
+int rt_scene_clone(const rt_scene *scene, int device, rt_scene **out);
 /* The host half of rt_scene_create alone (no device is touched): the returned
  * scene answers rt_scene_get_info / rt_scene_get_bvh and nothing else; every
  * render entry point rejects it with RT_ERR_NO_DEVICE. */

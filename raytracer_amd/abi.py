@@ -113,7 +113,7 @@ class SceneInfo(C.Structure):
 
 # every symbol include/raytracer_amd.h and include/raytracer_tokens.h declare
 EXPORTED_SYMBOLS = [
-    "rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_create_host", "rt_scene_destroy", "rt_scene_get_info",
+    "rt_device_count", "rt_last_error", "rt_scene_create", "rt_scene_clone", "rt_scene_create_host", "rt_scene_destroy", "rt_scene_get_info",
     "rt_scene_get_bvh", "rt_scene_set_camera", "rt_render", "rt_render_device", "rt_tile_count", "rt_tiles_live",
     "rt_sequence_create", "rt_sequence_destroy", "rt_sequence_frames_in_flight", "rt_sequence_submit", "rt_sequence_wait",
     "rt_multi_create", "rt_multi_create_pipelined", "rt_multi_frames_in_flight", "rt_multi_submit", "rt_multi_wait", "rt_multi_destroy", "rt_multi_device_count", "rt_multi_set_camera", "rt_multi_render", "rt_multi_render_device",
@@ -140,6 +140,7 @@ def load_library(path=None):
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_int, C.POINTER(vp)]
     lib.rt_scene_create_host.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
+    lib.rt_scene_clone.argtypes = [vp, C.c_int, C.POINTER(vp)]
     lib.rt_scene_destroy.argtypes = [vp]
     lib.rt_scene_destroy.restype = None
     lib.rt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]

@@ -89,6 +89,14 @@ class Scene:
         self.device = device
         del keep
 
+    def clone(self, device=None):
+        """A replica on `device` (default: this scene's) that shares this scene's host side (rt_scene_clone)."""
+        h = C.c_void_p()
+        _check(self._lib, self._lib.rt_scene_clone(self._h, self.device if device is None else device, C.byref(h)))
+        other = Scene.__new__(Scene)
+        other._lib, other.data, other._h, other.device = self._lib, self.data, h, self.device if device is None else device
+        return other
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.rt_scene_destroy(self._h)

@@ -177,7 +177,7 @@ void core_destroy(Core *m)
 }
 
 /* one complete set of replicas, streams, part threads for the device list; returns null with the error text set */
-Core *core_create(const rt_scene_desc *desc, const int *devices, int n_devices, int flags, int visible, int *status)
+Core *core_create(const rt_scene_desc *desc, const rt_scene *first, const int *devices, int n_devices, int flags, int visible, int *status)
 {
    Core *m = new (std::nothrow) Core();
    if (!m) { rt_set_error("rt_multi_create: out of memory"); *status = RT_ERR_BAD_ARGUMENT; return nullptr; }
@@ -191,8 +191,10 @@ Core *core_create(const rt_scene_desc *desc, const int *devices, int n_devices, 
       }
       Part &p = m->parts[(size_t)k];
       p.device = dev;
-      /* the scene is replicated: one copy of the flattened scene and its BVH per part, in that part's device memory */
-      int rc = rt_scene_create(desc, dev, flags, &p.scene);
+      /* the scene is replicated: one copy of the flattened scene and its trees per part, in that part's device memory;
+       * flattened and built once, on the host, by the first part of all */
+      const rt_scene *built = first ? first : (k > 0 ? m->parts[0].scene : nullptr);
+      int rc = built ? rt_scene_clone(built, dev, &p.scene) : rt_scene_create(desc, dev, flags, &p.scene);
       if (rc != RT_OK) { std::string why = rt_last_error(); return give_up(rc, why); }
       if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) != hipSuccess)
          return give_up(RT_ERR_HIP, "stream creation failed");
@@ -267,7 +269,7 @@ extern "C" int rt_multi_create_pipelined(const rt_scene_desc *desc, const int *d
    m->camera = desc->camera; m->has_camera = desc->has_camera != 0;
    for (int f = 0; f < frames_in_flight; f++) {
       int status = RT_OK;
-      Core *c = core_create(desc, devices, n_devices, flags, visible, &status);
+      Core *c = core_create(desc, m->cores.empty() ? nullptr : m->cores[0]->parts[0].scene, devices, n_devices, flags, visible, &status);
       if (!c) { std::string why = rt_last_error(); return fail(m, status, "%s", why.c_str()); }
       m->cores.push_back(c);
    }

@@ -53,7 +53,8 @@ extern "C" void rt_scene_destroy(rt_scene *s)
       (void)hipStreamDestroy(s->chain);
       (void)hipEventDestroy(s->ev_begin); (void)hipEventDestroy(s->ev_end);
    }
-   rt_flat_scene_free(&s->host);
+   /* (the host arrays go with their last owner: a scene and its clones share them) */
+   if (!s->host_owner) rt_flat_scene_free(&s->host);
    delete s;
 }
 
@@ -91,6 +92,7 @@ extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
    auto t0 = std::chrono::steady_clock::now();
    int st = rt_flatten_scene(desc, &s->host);
    if (st != RT_OK) { delete s; return st; }
+   s->host_owner = std::make_shared<HostScene>(); s->host_owner->flat = s->host;
    s->ms_build_host = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
    s->cull_enabled = 1;
    scene_bounds(s);
@@ -98,25 +100,37 @@ extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
    return RT_OK;
 }
 
-extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags, rt_scene **out)
+/* a scene object for `device` with nothing in it yet */
+static int scene_begin(int device, int flags, const rt_camera &camera, int has_camera, const char *who, rt_scene **out)
 {
-   if (!desc || !out) { rt_set_error("rt_scene_create: null argument"); return RT_ERR_BAD_ARGUMENT; }
    *out = nullptr;
    int ndev = rt_device_count();
    if (ndev <= 0) { rt_set_error("no HIP device: the render path has no CPU fallback"); return RT_ERR_NO_DEVICE; }
-   if (device < 0 || device >= ndev) { rt_set_error("device %d out of range (%d devices)", device, ndev); return RT_ERR_BAD_ARGUMENT; }
+   if (device < 0 || device >= ndev) { rt_set_error("%s: device %d out of range (%d devices)", who, device, ndev); return RT_ERR_BAD_ARGUMENT; }
    HIP_TRY(hipSetDevice(device));
 
    rt_scene *s = new (std::nothrow) rt_scene();
    if (!s) return RT_ERR_BAD_ARGUMENT;
    memset(&s->host, 0, sizeof s->host);
-   s->device = device; s->flags = flags; s->streams_ok = false; s->ms_build_device = 0.0f;
+   s->device = device; s->flags = flags; s->streams_ok = false; s->ms_build_device = 0.0f; s->ms_build_host = 0.0f;
    s->dev_blob = nullptr; s->d_ctr = nullptr; s->d_stats = nullptr; s->h_stats = nullptr; s->node_factor = 2.0f;
    s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false; s->order_dirty = true;
    s->d_lists = nullptr; s->list_cap = first_list_cap(); s->list_waves = 0; s->d_spill = nullptr; s->d_frame = nullptr; s->frame_cap = 0;
-   s->camera = desc->camera; s->has_camera = desc->has_camera;
+   s->camera = camera; s->has_camera = has_camera;
    scene_tuning(s);
    { char *unused = nullptr; (void)rt_scratch_address(device, &unused); }   /* this device's static working memory (rt_trace_rays_static), looked up while the device is current; a failure is reported by that call */
+   *out = s;
+   return RT_OK;
+}
+
+static int scene_upload(rt_scene *s, int flags);
+
+extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags, rt_scene **out)
+{
+   if (!desc || !out) { rt_set_error("rt_scene_create: null argument"); return RT_ERR_BAD_ARGUMENT; }
+   rt_scene *s = nullptr;
+   { int rc = scene_begin(device, flags, desc->camera, desc->has_camera, "rt_scene_create", &s); if (rc != RT_OK) { *out = nullptr; return rc; } }
+   *out = nullptr;
 
    if (!rt_env_int("RT_MISS_FILTER", 1, true)) flags |= RT_SCENE_NO_FILTER;      /* for A/B runs; frames are the same either way */
    auto t0 = std::chrono::steady_clock::now();
@@ -134,9 +148,39 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
          for (int j = 0; j < 12; j++)
             if (!(std::fabs(s->host.nodes[k].lmin[j]) <= 1.099511627776e12f)) s->host.bounds_in_range = 0;
    }
-   auto t1 = std::chrono::steady_clock::now();
-   s->ms_build_host = std::chrono::duration<float, std::milli>(t1 - t0).count();
+   s->host_owner = std::make_shared<HostScene>(); s->host_owner->flat = s->host;      /* from here on the arrays are the owner's */
+   s->ms_build_host = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+   st = scene_upload(s, flags);
+   if (st != RT_OK) return st;      /* (scene_upload has destroyed the scene) */
+   *out = s;
+   return RT_OK;
+}
 
+/* A replica of a scene on another device (or the same one): the flattened scene and its trees, built once on the host,
+ * are shared; what is made anew is everything on the device. */
+extern "C" int rt_scene_clone(const rt_scene *src, int device, rt_scene **out)
+{
+   if (!src || !out) { rt_set_error("rt_scene_clone: null argument"); return RT_ERR_BAD_ARGUMENT; }
+   *out = nullptr;
+   if (src->device < 0 || !src->host_owner) { rt_set_error("rt_scene_clone: the scene has no device side to copy (made with rt_scene_create_host)"); return RT_ERR_BAD_ARGUMENT; }
+   rt_scene *s = nullptr;
+   { int rc = scene_begin(device, src->flags, src->camera, src->has_camera, "rt_scene_clone", &s); if (rc != RT_OK) return rc; }
+   s->host = src->host; s->host_owner = src->host_owner;
+   s->ms_build_device = 0.0f;
+   int flags = src->flags;
+   if (!rt_env_int("RT_MISS_FILTER", 1, true)) flags |= RT_SCENE_NO_FILTER;
+   int st = scene_upload(s, flags);
+   if (st != RT_OK) return st;
+   *out = s;
+   return RT_OK;
+}
+
+/* the device side of a scene whose host side is complete; on failure the scene is destroyed */
+static int scene_upload(rt_scene *s, int flags)
+{
+   auto t1 = std::chrono::steady_clock::now();
+   hipError_t e_dev = hipSetDevice(s->device);
+   if (e_dev != hipSuccess) { rt_set_error("hipSetDevice(%d) failed: %s", s->device, hipGetErrorString(e_dev)); rt_scene_destroy(s); return RT_ERR_HIP; }
    const rt_flat_scene &h = s->host;
    /* On the device the primitives are numbered by their place among the tree's leaves (formBVH's sorted order), not
     * by the caller's order: a leaf reference is then its position, which a tree with computed child slots needs, and
@@ -317,7 +361,6 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
    if (e != hipSuccess) { rt_set_error("scene upload failed: %s", hipGetErrorString(e)); rt_scene_destroy(s); return RT_ERR_HIP; }
    auto t2 = std::chrono::steady_clock::now();
    s->ms_upload = std::chrono::duration<float, std::milli>(t2 - t1).count();
-   *out = s;
    return RT_OK;
 }
 

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <memory>
 #include <vector>
 
 #include "rt_kernel_types.h"
@@ -27,8 +28,18 @@ struct Arena {
    size_t cap = 0, used = 0;
 };
 
+/* owner of a flattened scene's host arrays */
+struct HostScene {
+   rt_flat_scene flat;
+   HostScene() { memset(&flat, 0, sizeof flat); }
+   ~HostScene() { rt_flat_scene_free(&flat); }
+   HostScene(const HostScene &) = delete;
+   HostScene &operator=(const HostScene &) = delete;
+};
+
 struct rt_scene {
-   rt_flat_scene host;
+   rt_flat_scene host;      /* the flattened scene and its trees on the host; the arrays belong to host_owner */
+   std::shared_ptr<HostScene> host_owner;   /* shared by the replicas of a scene (rt_scene_clone): built once, freed with the last of them */
    int device;
    int flags;
    DScene d;

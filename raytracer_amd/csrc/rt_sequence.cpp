@@ -109,7 +109,8 @@ extern "C" int rt_sequence_create(const rt_scene_desc *desc, int device, int fla
    q->device = device;
    q->slots.resize((size_t)frames_in_flight);
    for (Slot &s : q->slots) {
-      int rc = rt_scene_create(desc, device, flags, &s.scene);
+      /* (flattened and built once; the other replicas share the first one's host side) */
+      int rc = q->slots[0].scene && &s != &q->slots[0] ? rt_scene_clone(q->slots[0].scene, device, &s.scene) : rt_scene_create(desc, device, flags, &s.scene);
       if (rc != RT_OK) { std::string why = rt_last_error(); rt_sequence_destroy(q); rt_set_error("%s", why.c_str()); return rc; }
    }
    /* The streams are made one after the other, after everything else: the runtime deals its few hardware queues out to
