@@ -92,6 +92,7 @@ typedef struct rt_flat_scene {
     * squeezed by its transform).  The largest of 1 / radius over the scene's spheres, in world units, with that
     * squeeze folded in; 0 for a scene without spheres.  See RayCtx::wide. */
    float sphere_coeff;
+   float origin_reach;      /* rays that start within this many units of the origin of the coordinates, on every axis, may use the second tree (its boxes are widened for them) */
 } rt_flat_scene;
 
 #ifdef __cplusplus

@@ -104,7 +104,6 @@ struct RayCtx {
    float yx, yy, yz;      /* RN(1/d) per axis (unused on a parallel axis) */
    unsigned par;          /* bit k < 3 set: axis k is "parallel", |d_k| < EPSILON (GeometryUtil.h:16,23,30); RT_PAR_NO_FILTER: see there */
    bool fast;             /* every value the short box test divides is inside rt_div's safe range */
-   float wide;            /* how far the boxes of the second tree are widened for this ray, on every side (set by the traversal kernel) */
 };
 #define RT_PAR_AXES 7u
 #define RT_PAR_NO_FILTER 8u    /* this ray does not use the second tree (its margins would not cover what the primitive tests may be off by) */
@@ -117,7 +116,6 @@ __device__ __forceinline__ RayCtx make_ctx(const Ray &r)
    bool px = is_zero(r.d.x), py = is_zero(r.d.y), pz = is_zero(r.d.z);
    c.par = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u);
    /* a parallel axis is never divided by, so only the other axes' directions have to be in range */
-   c.wide = 0.0f;
    c.fast = (r.o.x == 0.0f || in_div_range(r.o.x)) && (r.o.y == 0.0f || in_div_range(r.o.y)) &&
             (r.o.z == 0.0f || in_div_range(r.o.z)) && (px || in_div_range(r.d.x)) && (py || in_div_range(r.d.y)) &&
             (pz || in_div_range(r.d.z));
@@ -167,16 +165,13 @@ __device__ __forceinline__ float slab_literal(const Ray &r, float mnx, float mny
 /* the two numbers the box test turns on: where the ray enters the last of the three slabs (A) and where it leaves the
  * first (B), with the reference's treatment of parallel axes; miss / strict as described above */
 struct SlabAB { float A, B; bool miss, strict; };
-/* `up` / `dn`: the ray's origin moved by the widening (origin + w, origin - w per axis): a box wider by w on every side
- * is met exactly when the lower bounds are measured from `up` and the upper ones from `dn`.  With w = 0 both are the
- * origin and this is the reference's arithmetic. */
 template <bool PAR>
-__device__ __forceinline__ SlabAB slab_ab(const RayCtx &c, F3 up, F3 dn, float mnx, float mny, float mnz, float mxx, float mxy, float mxz)
+__device__ __forceinline__ SlabAB slab_ab(const RayCtx &c, float mnx, float mny, float mnz, float mxx, float mxy, float mxz)
 {
    const Ray &r = c.r;
-   float x1 = rt_div(mnx - up.x, r.d.x, c.yx), x2 = rt_div(mxx - dn.x, r.d.x, c.yx);
-   float y1 = rt_div(mny - up.y, r.d.y, c.yy), y2 = rt_div(mxy - dn.y, r.d.y, c.yy);
-   float z1 = rt_div(mnz - up.z, r.d.z, c.yz), z2 = rt_div(mxz - dn.z, r.d.z, c.yz);
+   float x1 = rt_div(mnx - r.o.x, r.d.x, c.yx), x2 = rt_div(mxx - r.o.x, r.d.x, c.yx);
+   float y1 = rt_div(mny - r.o.y, r.d.y, c.yy), y2 = rt_div(mxy - r.o.y, r.d.y, c.yy);
+   float z1 = rt_div(mnz - r.o.z, r.d.z, c.yz), z2 = rt_div(mxz - r.o.z, r.d.z, c.yz);
    float xl = fminf(x1, x2), xh = fmaxf(x1, x2);
    float yl = fminf(y1, y2), yh = fmaxf(y1, y2);
    float zl = fminf(z1, z2), zh = fmaxf(z1, z2);
@@ -186,8 +181,8 @@ __device__ __forceinline__ SlabAB slab_ab(const RayCtx &c, F3 up, F3 dn, float m
       xl = px ? -FLT_MAX : xl; xh = px ? FLT_MAX : xh;
       yl = py ? -FLT_MAX : yl; yh = py ? FLT_MAX : yh;
       zl = pz ? -FLT_MAX : zl; zh = pz ? FLT_MAX : zh;
-      s.miss = (px && (up.x < mnx || dn.x > mxx)) || (py && (up.y < mny || dn.y > mxy)) ||
-               (pz && (up.z < mnz || dn.z > mxz));
+      s.miss = (px && (r.o.x < mnx || r.o.x > mxx)) || (py && (r.o.y < mny || r.o.y > mxy)) ||
+               (pz && (r.o.z < mnz || r.o.z > mxz));
       s.strict = (!px || (r.o.x > mnx && r.o.x < mxx)) && (!py || (r.o.y > mny && r.o.y < mxy)) &&
                  (!pz || (r.o.z > mnz && r.o.z < mxz));
    }
@@ -208,7 +203,7 @@ template <bool PAR>
 __device__ __forceinline__ float slab_fast(const RayCtx &c, float mnx, float mny, float mnz,
                                            float mxx, float mxy, float mxz)
 {
-   return slab_value(slab_ab<PAR>(c, c.r.o, c.r.o, mnx, mny, mnz, mxx, mxy, mxz));
+   return slab_value(slab_ab<PAR>(c, mnx, mny, mnz, mxx, mxy, mxz));
 }
 /* How far behind a ray's origin a box of the second tree may end and still be entered: a primitive is accepted from
  * EPSILON behind the origin on, and what a sphere's test reports may lie RT_SLACK_MAX in front of the sphere's box. */

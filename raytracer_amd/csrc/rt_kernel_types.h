@@ -38,7 +38,7 @@ struct DScene {
    /* for the margins a ray gives the second tree (make_ray_ctx): the middle of the box that holds the scene's spheres,
     * half its diagonal, and rt_flat_scene::sphere_coeff */
    float mid_x, mid_y, mid_z, mid_rad, sphere_coeff;
-   float origin_coeff;   /* RayCtx::wide as a fraction of the origin's largest coordinate (2^-20) */
+   float origin_reach;   /* a ray that starts further than this from the origin of the coordinates, on some axis, does not use the second tree (whose boxes are widened for the others, see the host's tree build) */
    int verify_jump;      /* every box of the reference's tree lies inside its parent's (checked when the scene is made): a ray
                           * on its way down to one leaf may go from the root straight to the leaf's parent, see the node step */
 };

@@ -313,10 +313,9 @@ static int scene_upload(rt_scene *s, int flags)
       s->d.verify_jump = nested && rt_env_int("RT_VERIFY_JUMP", 1, true) ? 1 : 0;
       s->guide_ok = s->guide_ok && nested && rt_env_int("RT_GUIDE", 1, true) != 0;
    }
-   s->d.sphere_coeff = h.sphere_coeff; s->d.origin_coeff = 9.5367431640625e-7f;
+   s->d.sphere_coeff = h.sphere_coeff; s->d.origin_reach = h.origin_reach;
    /* (for measurements: what the two margins cost) */
    if (const char *e = getenv("RT_SPHERE_MARGIN")) s->d.sphere_coeff *= (float)atof(e);
-   if (const char *e = getenv("RT_ORIGIN_MARGIN")) s->d.origin_coeff *= (float)atof(e);
    /* a bounce ray needs a material with reflection or refraction above 0 (kernel.cu:360-374) */
    s->can_bounce = false;
    for (int k = 0; k < h.n_materials; k++) if (h.materials[k].refl > 0.0f || h.materials[k].refr > 0.0f) s->can_bounce = true;

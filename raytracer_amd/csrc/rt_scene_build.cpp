@@ -626,6 +626,33 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
       box_centers.resize((size_t)n);
       for (int i = 0; i < n; i++) box_centers[(size_t)i] = box_center(b.boxes[(size_t)i]);
    }
+   /* How far from the origin of the coordinates a ray may start and still use the second tree.  The two trees' box tests
+    * round the differences they take from a ray's origin differently (their boxes differ), by a few units in the last place
+    * of the origin's coordinates -- 1e-4 per subtraction for a light a thousand units from a scene of size one.  The second
+    * tree's boxes are widened by 2^-20 of this reach, eight times that rounding, and a ray that starts further out than
+    * the reach does not use the tree (k_trace).  The reach: twice the largest coordinate among the primitives' boxes (where
+    * bounce rays start), the lights (where feelers start) and the camera with its image plane (where primaries start), so
+    * that a camera may move about. */
+   float origin_reach = 0.0f;
+   {
+      double far = 1.0;
+      for (int i = 0; i < n; i++) {
+         const Box3 &bx = b.boxes[(size_t)i];
+         const float v[6] = {bx.mn.x, bx.mn.y, bx.mn.z, bx.mx.x, bx.mx.y, bx.mx.z};
+         for (float c : v) if (std::fabs((double)c) > far && std::isfinite(c)) far = std::fabs((double)c);
+      }
+      for (int i = 0; i < d->n_lights; i++)
+         for (int j = 0; j < 3; j++) { const double c = std::fabs((double)d->lights[i].pos[j]); if (c > far && std::isfinite(c)) far = c; }
+      if (d->has_camera)
+         for (int j = 0; j < 3; j++) {
+            const double c = std::fabs((double)d->camera.pos[j]) + std::fabs((double)d->camera.right[j]) + std::fabs((double)d->camera.up[j]);
+            if (c > far && std::isfinite(c)) far = c;
+         }
+      far *= 2.0;
+      origin_reach = far < 1e30 ? (float)far : 1e30f;
+   }
+   float origin_pad = origin_reach * 9.5367431640625e-7f;      /* 2^-20 */
+   if (const char *e = getenv("RT_ORIGIN_MARGIN")) origin_pad *= (float)atof(e);      /* (for measurements: what the margin costs) */
    std::vector<rt_bvh_node> filter;
    int filter_depth = 0;
    int filter_min = RT_FILTER_MIN_PRIMS;
@@ -651,7 +678,7 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
          for (size_t k = 0; k < filter.size(); k++) {
             float *v = filter[k].lmin;      /* lmin, lmax, rmin, rmax */
             for (int j = 0; j < 12; j++) {
-               const float pad = 1e-4f + 8e-6f * std::fabs(v[j]);
+               const float pad = 1e-4f + 8e-6f * std::fabs(v[j]) + origin_pad;
                const bool is_max = (j / 3) & 1;
                v[j] = is_max ? v[j] + pad : v[j] - pad;
             }
@@ -769,6 +796,7 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
          if (!(k <= 3.0e38)) coeff = 3.0e38; else if (k > coeff) coeff = k;
       }
       out->sphere_coeff = (float)coeff;
+      out->origin_reach = origin_reach;
    }
    for (size_t k = 0; k < flat.size(); k++) {
       const float *v = flat[k].lmin;   /* lmin, lmax, rmin, rmax are 12 consecutive floats */

@@ -154,8 +154,10 @@ __device__ __forceinline__ bool tie_prefers_new(const rt_dev_prim *prims, const 
  * reference could test as long as its box test never turns away a box the reference's would let the ray into.  The
  * two tests round differently (their boxes differ), by a few units in the last place of the differences they take
  * from the ray's origin -- 1e-4 per subtraction for a light a thousand units from a scene of size one.  Beside the
- * widening its boxes carry for the size of their own coordinates, the second tree's boxes are therefore widened, for
- * this ray, by 2^-20 of the origin's largest coordinate (RayCtx::wide; eight times the box test's rounding).
+ * widening its boxes carry for the size of their own coordinates, the second tree's boxes are therefore widened, when
+ * the tree is built, by 2^-20 of the scene's `origin_reach` (eight times the box test's rounding for an origin that far
+ * out), and a ray that starts further out than that does not use the tree.  (Each ray widening the boxes by its own
+ * origin's share, in the node step, was tighter and cost 2.5 % of the frame.)
  *
  * What remains is where along the ray a primitive reports its hit.  The second tree does not enter boxes that start
  * behind the stretch a ray cares about, on the grounds that a primitive is met no earlier than its box.  Triangles
@@ -168,7 +170,7 @@ __device__ __forceinline__ bool tie_prefers_new(const rt_dev_prim *prims, const 
 __device__ __forceinline__ RayCtx make_ray_ctx(const DScene &sc, const Ray &r, float &slack)
 {
    RayCtx c = make_ctx(r);
-   c.wide = sc.origin_coeff * fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
+   if (!(fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z)) <= sc.origin_reach)) c.par |= RT_PAR_NO_FILTER;
    slack = 0.0f;
    if (sc.sphere_coeff > 0.0f) {
       const F3 e = r.o - mk3(sc.mid_x, sc.mid_y, sc.mid_z);
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
    bool burst_filter = false;          /* wave-uniform: some lane of the current burst of node steps is in the second tree */
    bool burst_guided = false;          /* wave-uniform: some lane of the current burst makes a guided walk */
    RayCtx c;
-   c.r.o = mk3(0, 0, 0); c.r.d = mk3(1, 1, 1); c.yx = c.yy = c.yz = 1.0f; c.par = 0; c.fast = true; c.wide = 0.0f;
+   c.r.o = mk3(0, 0, 0); c.r.d = mk3(1, 1, 1); c.yx = c.yy = c.yz = 1.0f; c.par = 0; c.fast = true;
    float t = FLT_MAX, toBeat = -FLT_MAX;
    int closest = -1, cur = RT_CUR_IDLE, sp = 0, tag = 0;   /* cur: node index, ~primitive, or RT_CUR_IDLE while the lane has no ray */
    int mode = MODE_EXTEND;             /* OUT_CHAIN: what this lane's ray is; tag: depth level + 1 (closest-hit rays) or the light (feelers) */
@@ -578,11 +580,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
          left = slab_literal(c.r, na.x, na.y, na.z, na.w, nb.x, nb.y);
          right = slab_literal(c.r, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w);
       } else {
-         /* in the second tree the boxes are wider by the ray's own margin (RayCtx::wide); in the reference's, as they are */
-         const float w = (TWO && (mode & MODE_FILTER)) ? c.wide : 0.0f;
-         const F3 up = mk3(c.r.o.x + w, c.r.o.y + w, c.r.o.z + w), dn = mk3(c.r.o.x - w, c.r.o.y - w, c.r.o.z - w);
-         SlabAB sl = slab_ab<VARIANT == 1>(c, up, dn, na.x, na.y, na.z, na.w, nb.x, nb.y);
-         SlabAB sr = slab_ab<VARIANT == 1>(c, up, dn, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w);
+         SlabAB sl = slab_ab<VARIANT == 1>(c, na.x, na.y, na.z, na.w, nb.x, nb.y);
+         SlabAB sr = slab_ab<VARIANT == 1>(c, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w);
          left = slab_value(sl); right = slab_value(sr);
          if (TWO && burst_filter) {
             /* a ray still in the miss filter's tree asks the filter's question of the same two numbers */

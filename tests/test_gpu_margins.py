@@ -141,3 +141,32 @@ def test_balls2_lit_from_afar():
         moved = synth.similar(sd, 1.0, move_camera=False, move_lights=False)
         moved.lights["pos"] = sd.lights["pos"] * np.float32(far)
         on_and_off(moved, 320, 180)
+
+
+@pytest.mark.parametrize("far", [50.0, 3.0e3, 2.0e5])
+def test_camera_moved_beyond_the_reach_the_second_tree_was_built_for(far):
+    """The second tree's boxes are widened for ray origins up to twice as far from the origin of the coordinates as the
+    scene, its lights and its first camera reach; a camera moved further out afterwards sends rays that must leave the
+    tree alone.  The frames from out there are the same bytes with the second tree and without it."""
+    sd = synth.random_scene(91, n_spheres=60, n_triangles=80, n_boxes=20, n_smooth=30, n_planes=0, n_lights=2)
+    frames = []
+    for use in (True, False):
+        with ra.Scene(sd, miss_filter=use, counters=True) as sc:
+            near, st_near = sc.render(160, 120, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, 3)
+            pos = np.array([0.3 * far, 0.2 * far, far], np.float32)
+            sc.set_camera(pos, np.array([0, 1, 0], np.float32), np.array([1.3333, 0, 0], np.float32), np.zeros(3, np.float32))
+            # (seen from that far the scene is a speck: a narrow image plane keeps it in the picture)
+            sc.set_camera(pos, np.array([0, 8.0 / far, 0], np.float32), np.array([10.6 / far, 0, 0], np.float32), np.zeros(3, np.float32))
+            out, st_out = sc.render(160, 120, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, 3)
+            prim, t = sc.trace_primary(160, 120, 1, abi.RT_JITTER_HASH, 3)
+            frames.append((near, out, prim, t, st_near, st_out))
+    (n1, o1, p1, t1, sn1, so1), (n0, o0, p0, t0, sn0, so0) = frames
+    assert n1.tobytes() == n0.tobytes() and o1.tobytes() == o0.tobytes()
+    assert np.array_equal(p1, p0) and np.array_equal(t1.view(np.uint32), t0.view(np.uint32))
+    assert (p1 >= 0).sum() > 200                      # the scene is in the picture
+    for k in COUNTS:
+        assert so1[k] == so0[k], k
+    assert sn1["hits_certified"] > 0                  # near by, the second tree answers
+    if far > 1.0e3:
+        # from beyond the reach the primaries make the reference's walk (bounce rays start on the scene and still use the tree)
+        assert so1["hits_certified"] < int((p1 >= 0).sum()) // 4
