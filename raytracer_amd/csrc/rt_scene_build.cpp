@@ -641,6 +641,9 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
          const float v[6] = {bx.mn.x, bx.mn.y, bx.mn.z, bx.mx.x, bx.mx.y, bx.mx.z};
          for (float c : v) if (std::fabs((double)c) > far && std::isfinite(c)) far = std::fabs((double)c);
       }
+      /* (a light or a camera more than a thousand times further out than the primitives is left outside the reach:
+       * widening every box for its sake would cost all the other rays the tree's tightness) */
+      const double most = 1024.0 * far;
       for (int i = 0; i < d->n_lights; i++)
          for (int j = 0; j < 3; j++) { const double c = std::fabs((double)d->lights[i].pos[j]); if (c > far && std::isfinite(c)) far = c; }
       if (d->has_camera)
@@ -649,6 +652,7 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
             if (c > far && std::isfinite(c)) far = c;
          }
       far *= 2.0;
+      if (far > most) far = most;
       origin_reach = far < 1e30 ? (float)far : 1e30f;
    }
    float origin_pad = origin_reach * 9.5367431640625e-7f;      /* 2^-20 */
