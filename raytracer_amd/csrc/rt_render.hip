@@ -629,9 +629,18 @@ static int render_impl(rt_scene *s, const rt_render_params *p, int view, void *o
       if (max_rec > 1 && wanted * 1.1 > F) s->node_factor = (float)(wanted * 1.25 < 64.0 ? wanted * 1.25 : 64.0);
       /* (the costs are the rays' own step counts: a still camera brings the same ones back every frame, and then the
        * order stands as it is) */
-      const bool same_costs = track_cost && s->order_valid && memcmp(key, s->order_key, sizeof key) == 0 && !s->last_cost.empty() &&
-                              s->last_cost.size() == 2 * (size_t)n_sel &&
-                              memcmp(s->last_cost.data(), s->h_tile_cost, 2 * sizeof(unsigned) * (size_t)n_sel) == 0;
+      /* (nearly the same ones: a guided walk's first steps depend on where in its wave's burst it began, so a few costs
+       * move by a few steps from frame to frame.  The order stands while no tile's cost has moved by more than a
+       * sixteenth, or eight steps, from the costs the order was made from; ranking 2 000 tiles anew costs the host 50 us, a
+       * twentieth of the headline frame.) */
+      bool same_costs = track_cost && s->order_valid && memcmp(key, s->order_key, sizeof key) == 0 && !s->last_cost.empty() &&
+                        s->last_cost.size() == 2 * (size_t)n_sel;
+      for (long long k = 0; k < n_sel && same_costs; k++)
+         for (int word = 0; word < (s->order_mean_weight > 0.0 ? 2 : 1); word++) {
+            const unsigned was = s->last_cost[2 * (size_t)k + word], is = s->h_tile_cost[2 * k + word];
+            const unsigned moved = was > is ? was - is : is - was;
+            if (moved > 8u && moved > was / 16u) same_costs = false;
+         }
       if (track_cost && !same_costs) {
          s->last_cost.assign(s->h_tile_cost, s->h_tile_cost + 2 * (size_t)n_sel);
          /* Costliest first, in a few classes of equal size (by rank of the tile's longest chain); tiles of a class stay
