@@ -49,6 +49,18 @@ def test_256_lights():
     assert st["rays_shadow"] > 200 * st["shade_nodes"]
 
 
+def test_seventy_thousand_triangles_on_the_reference_tree():
+    """A scene large enough for the host's threaded paths (per-primitive records filled from several threads, 72 200
+    distinct materials through the hash table, radix-sorted rounds of the reference's tree build) against the oracle, whose
+    scene construction is its own: ids, distances, ray counts and colours as for the small scenes."""
+    sd = synth.terrain(190, 190, lights_per_side=2)
+    with ra.Scene(sd, host_only=True) as sc:
+        info = sc.info()
+    assert info["n_bvh_prims"] == 72_200 and info["n_materials"] > 60_000
+    st = compare(sd, 96, 72)
+    assert st["rays_shadow"] > 0
+
+
 def test_full_binary_bounce_trees():
     sd = synth.glassy(ra.SceneData.load(os.path.join(GOLDEN, "scenes", "dragon_large_tris.npz")))
     st = compare(sd, 320, 180)
