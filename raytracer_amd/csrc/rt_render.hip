@@ -210,7 +210,7 @@ static ChunkCtr chunk_ctr(const rt_scene *s, int ring)
  * thousandth of its size and of its distance from E plus the padding the tree's levels add to their boxes
  * (BoundingBox.h: 1e-4 per construction).  Computed in double.  Scenes with planes are not culled (planes are
  * tested for every ray, kernel.cu:189-196). */
-static void cull_tiles(const rt_scene *s, const DCamera &cam, const DGrid &g, int n_sel, std::vector<unsigned char> &live, long long *n_live)
+static void cull_tiles(const rt_scene *s, const DCamera &cam, const DGrid &g, int n_sel, bool finer, std::vector<unsigned char> &live, long long *n_live)
 {
    live.assign((size_t)n_sel, 1);
    *n_live = n_sel;
@@ -229,8 +229,22 @@ static void cull_tiles(const rt_scene *s, const DCamera &cam, const DGrid &g, in
     * the last place of the camera position's coordinates: a camera far from the origin of the coordinates gets margins
     * that grow with that */
    const double pos_ulp = std::max(std::max(std::fabs((double)cam.pos.x), std::fabs((double)cam.pos.y)), std::fabs((double)cam.pos.z)) * (1.0 / 4194304.0);
-   const double pad = 1e-3 * (ext + dist) + 2e-4 * (double)(s->host.tree_depth + s->host.filter_depth + 4) + 1e-3 + 4.0 * pos_ulp * (2.0 + dist);
+   /* (a sphere seen from afar reports hits off its surface by up to 2^-22 distance^2 / radius, Sphere.h:42-66: that is
+    * allowed for too, twice over) */
+   const double pad = 1e-3 * (ext + dist) + 2e-4 * (double)(s->host.tree_depth + s->host.filter_depth + 4) + 1e-3 + 4.0 * pos_ulp * (2.0 + dist) +
+                      4.8e-7 * (double)s->host.sphere_coeff * (dist + ext) * (dist + ext);
    if (!std::isfinite(pad)) return;
+   /* the tree the finer test walks: the second tree if the scene has one (its boxes are the tighter ones), else the tree
+    * the rays are answered from; both hold every primitive's box in their leaves' places */
+   const rt_bvh_node *fine = nullptr;
+   if (finer && s->cull_fine > 0) {
+      if (s->host.n_filter_nodes > 0 && s->host.filter_nodes) fine = s->host.filter_nodes;
+      else if (s->host.n_nodes > 0 && s->host.nodes && s->host.root == 0) fine = s->host.nodes;
+   }
+   const int fine_budget = s->cull_fine;
+   /* (the box that showed the tile before this one to be in sight is looked at first: a floor seen through every tile
+    * answers at once) */
+   float seen_mn[3] = {0, 0, 0}, seen_mx[3] = {0, 0, 0}; bool have_seen = false;
    for (int j = 0; j < 3; j++) { lo[j] = s->bounds_lo[j] - pad; hi[j] = s->bounds_hi[j] + pad; }
    double corner[8][3];
    for (int c = 0; c < 8; c++)
@@ -276,6 +290,45 @@ static void cull_tiles(const rt_scene *s, const DCamera &cam, const DGrid &g, in
             for (int c = 0; c < 8 && all_behind; c++) all_behind = dot(mid, corner[c]) < 0.0;
             outside = all_behind;
          }
+      }
+      if (!outside && fine) {
+         /* The scene's box is in sight of the tile; is any primitive's?  Down the tree from its root, leaving out every
+          * box that lies wholly beyond one of the four side planes (its corner furthest on the inner side is still
+          * outside), until a leaf's box is found in sight -- or the budget of boxes is spent, which counts as found. */
+         double pn[4][3]; int np_ = 0;
+         for (int e = 0; e < 4; e++) {
+            double nrm[3]; cross(edge[e][0], edge[e][1], nrm);
+            const double len = std::sqrt(dot(nrm, nrm)), m = dot(nrm, mid);
+            if (!(len > 0.0) || !std::isfinite(len) || !(std::fabs(m) > 1e-9 * len)) continue;
+            const double sign = m > 0.0 ? 1.0 : -1.0;
+            for (int j = 0; j < 3; j++) pn[np_][j] = sign * nrm[j];
+            np_++;
+         }
+         auto in_sight = [&](const float *mn, const float *mx) {
+            for (int e = 0; e < np_; e++) {
+               double most = 0.0;
+               for (int j = 0; j < 3; j++) most += pn[e][j] * ((pn[e][j] > 0.0 ? (double)mx[j] + pad : (double)mn[j] - pad) - E[j]);
+               if (most < 0.0) return false;
+            }
+            return true;
+         };
+         bool found = np_ < 4;                  /* a degenerate pyramid: no finer answer */
+         if (!found && have_seen && in_sight(seen_mn, seen_mx)) found = true;
+         int spent = 0, sp = 0, stack[128];
+         stack[sp++] = 0;
+         while (sp > 0 && !found) {
+            const rt_bvh_node &nd = fine[stack[--sp]];
+            if (++spent > fine_budget) { found = true; break; }
+            const int32_t child[2] = {nd.right, nd.left};
+            const float *mn[2] = {nd.rmin, nd.lmin}, *mx[2] = {nd.rmax, nd.lmax};
+            for (int c = 0; c < 2 && !found; c++) {
+               if (!in_sight(mn[c], mx[c])) continue;
+               if (child[c] < 0) { found = true; have_seen = true; for (int j = 0; j < 3; j++) { seen_mn[j] = mn[c][j]; seen_mx[j] = mx[c][j]; } }
+               else if (sp < 128) stack[sp++] = child[c];
+               else found = true;
+            }
+         }
+         outside = !found;
       }
       if (outside) live[(size_t)k] = 0; else kept++;
    }
@@ -337,7 +390,7 @@ extern "C" int rt_tiles_live(const rt_scene *s, const rt_render_params *p, uint8
    g.tile_first = p->tile_first; g.tile_stride = tile_stride; g.ts = RT_TILE * sroot;
    std::vector<unsigned char> v((size_t)(n_sel > 0 ? n_sel : 0), 1);
    long long kept = n_sel;
-   if (n_sel > 0 && s->cull_enabled && s->host.n_planes == 0 && s->bounds_ok) cull_tiles(s, make_camera(s->camera), g, n_sel, v, &kept);
+   if (n_sel > 0 && s->cull_enabled && s->host.n_planes == 0 && s->bounds_ok) cull_tiles(s, make_camera(s->camera), g, n_sel, true, v, &kept);
    for (int k = 0; k < n_sel; k++) live[k] = v[(size_t)k];
    return RT_OK;
 }
@@ -476,9 +529,16 @@ static int render_impl(rt_scene *s, const rt_render_params *p, int view, void *o
       if (track_cost && fuse && s->cull_enabled && sc.n_planes == 0 && s->bounds_ok) {
          const float camf[12] = {cam.pos.x, cam.pos.y, cam.pos.z, cam.up.x, cam.up.y, cam.up.z, cam.right.x, cam.right.y, cam.right.z,
                                  cam.look_dir.x, cam.look_dir.y, cam.look_dir.z};
+         /* A new camera or frame geometry: the quick test against the scene's box now; the finer one, down the tree to
+          * the primitives' boxes (a few tenths of a millisecond of host time for a thousand tiles), when the next frame
+          * comes with the same camera -- a camera that moves every frame never waits for it. */
          if (s->n_live < 0 || memcmp(key, s->cull_key, sizeof key) != 0 || memcmp(camf, s->cull_cam, sizeof camf) != 0) {
-            cull_tiles(s, cam, g, n_sel, s->tile_live, &s->n_live);
+            cull_tiles(s, cam, g, n_sel, false, s->tile_live, &s->n_live);
             memcpy(s->cull_key, key, sizeof key); memcpy(s->cull_cam, camf, sizeof camf);
+            s->cull_stage = 1;
+         } else if (s->cull_stage == 1) {
+            if (s->cull_fine > 0 && s->n_live > 0) cull_tiles(s, cam, g, n_sel, true, s->tile_live, &s->n_live);
+            s->cull_stage = 2;
          }
          cull = s->n_live < n_sel;
       }

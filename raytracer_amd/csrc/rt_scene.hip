@@ -65,7 +65,7 @@ static void scene_bounds(rt_scene *s)
 {
    const rt_flat_scene &h = s->host;
    s->bounds_ok = h.n_prims > 0 && h.prim_boxes != nullptr && h.bounds_in_range;
-   s->n_live = -1; memset(s->cull_key, 0, sizeof s->cull_key); memset(s->cull_cam, 0, sizeof s->cull_cam);
+   s->n_live = -1; s->cull_stage = 0; memset(s->cull_key, 0, sizeof s->cull_key); memset(s->cull_cam, 0, sizeof s->cull_cam);
    for (int j = 0; j < 3; j++) { s->bounds_lo[j] = 1e300; s->bounds_hi[j] = -1e300; }
    for (int k = 0; k < h.n_prims && s->bounds_ok; k++)
       for (int j = 0; j < 3; j++) {
@@ -94,7 +94,7 @@ extern "C" int rt_scene_create_host(const rt_scene_desc *desc, rt_scene **out)
    if (st != RT_OK) { delete s; return st; }
    s->host_owner = std::make_shared<HostScene>(); s->host_owner->flat = s->host;
    s->ms_build_host = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-   s->cull_enabled = 1;
+   s->cull_enabled = 1; s->cull_fine = rt_env_int("RT_CULL_FINE", 256, true);
    scene_bounds(s);
    *out = s;
    return RT_OK;
@@ -420,6 +420,7 @@ static void scene_tuning(rt_scene *s)
    s->order_mean_weight = (double)rt_env_int("RT_ORDER_MEAN_WEIGHT", RT_ORDER_MEAN_WEIGHT, true);
    s->fuse_resolve = rt_env_int("RT_FUSE_RESOLVE", 1, true);
    s->cull_enabled = rt_env_int("RT_CULL_TILES", 1, true);
+   s->cull_fine = rt_env_int("RT_CULL_FINE", 256, true);
    s->skip_unlit = rt_env_int("RT_SKIP_UNLIT", 16, true);
    s->own_stream = rt_env_int("RT_OWN_STREAM", 0, true);
    {

@@ -76,6 +76,8 @@ struct rt_scene {
    /* Tiles no ray can meet anything through (see cull_tiles): recomputed when the camera or the frame geometry changes */
    int cull_enabled;                        /* RT_CULL_TILES, default on */
    bool bounds_ok; double bounds_lo[3], bounds_hi[3];   /* the box every primitive's bounding box lies in */
+   int cull_stage;          /* 1: the cached tile flags come from the quick test only; 2: from the finer one too */
+   int cull_fine;           /* most boxes of the tree the tile test looks at per tile before it gives up and traces the tile (0: only the scene's box is tested) */
    bool guide_ok;           /* the reference's tree on the device carries each node's range of leaves (TraceArgs::guide) */
    float tree_lo[3], tree_hi[3];   /* the box that holds both boxes of that tree's root */
    std::vector<unsigned char> tile_live;    /* per selected tile: 1 = has to be traced */

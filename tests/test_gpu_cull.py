@@ -175,3 +175,44 @@ def test_tile_parts():
                 outs.append((f, st))
         assert outs[0][0].tobytes() == outs[1][0].tobytes()
         assert outs[0][1]["rays_total"] == outs[1][1]["rays_total"]
+
+
+def test_finer_test_when_the_camera_stands_and_never_for_one_that_moves():
+    """The quick test (the scene's box) is made for a new camera at once; the finer one, down the tree to the primitives'
+    boxes, when the next frame comes with the same camera.  Sparse triangles in a wide box: the second frame leaves out
+    more tiles than the first, every frame is the same bytes as without any culling, and a camera that moves every
+    frame only ever gets the quick test."""
+    sd = synth.random_scene(52, n_spheres=0, n_boxes=0, n_planes=0, n_triangles=25, n_smooth=10)
+    look_from(sd, (0.0, 2.0, 30.0))
+    w, h = 640, 480
+    with scene_with(False, sd) as sc:
+        want, st0 = sc.render(w, h, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, 5)
+    with scene_with(True, sd) as sc:
+        culled = []
+        for _ in range(4):
+            got, st = sc.render(w, h, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, 5)
+            assert got.tobytes() == want.tobytes()
+            for k in ("rays_total", "rays_primary", "rays_shadow", "shade_nodes"):
+                assert st[k] == st0[k], k
+            culled.append(st["primaries_culled"])
+        assert culled[0] > 0 and culled[1] > culled[0] and culled[2] == culled[1] == culled[3]
+        # a camera that never stands still
+        quick = []
+        for k in range(4):
+            pos = np.array([0.01 * (k + 1), 2.0, 30.0], np.float32)
+            sc.set_camera(pos, sd.camera["up"], sd.camera["right"], sd.camera["look_at"])
+            _, st = sc.render(w, h, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, 5)
+            quick.append(st["primaries_culled"])
+        assert max(quick) < culled[1]
+    old = os.environ.get("RT_CULL_FINE")
+    os.environ["RT_CULL_FINE"] = "0"
+    try:
+        with scene_with(True, sd) as sc:
+            for _ in range(3):
+                got, st = sc.render(w, h, 1, abi.RT_PHONG, abi.RT_JITTER_HASH, 5)
+            assert got.tobytes() == want.tobytes() and st["primaries_culled"] == culled[0]
+    finally:
+        if old is None:
+            os.environ.pop("RT_CULL_FINE", None)
+        else:
+            os.environ["RT_CULL_FINE"] = old

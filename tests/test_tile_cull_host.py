@@ -1,12 +1,14 @@
 """Which tiles a frame leaves out of its launch, checked on the host (no GPU).
 
-rt_tiles_live says, per 32x32-pixel tile, whether any primary ray through it can reach the box that holds every
-primitive's bounding box.  Here the rays are restated in float64 with numpy from generateCameraRays
-(kernel.cu:477-498: origin pos + u/2 right + v/2 up, direction u/2 right + v/2 up + normalize(lookAt - pos), with
-u, v in [-1, 1] over the frame and a jitter of at most half a sample spacing) and tested against that box with the
-slab method: no ray of a tile that is left out may come anywhere near the box, from cameras near, far, inside,
-looking past the scene and looking away from it.
+rt_tiles_live says, per 32x32-pixel tile, whether any primary ray through it can reach a primitive's bounding box (first
+the box that holds them all, then, down the tree, the primitives' own).  Here the rays are restated in float64 with
+numpy from generateCameraRays (kernel.cu:477-498: origin pos + u/2 right + v/2 up, direction u/2 right + v/2 up +
+normalize(lookAt - pos), with u, v in [-1, 1] over the frame and a jitter of at most half a sample spacing) and tested
+against every primitive's box with the slab method: no ray of a tile that is left out may come anywhere near one, from
+cameras near, far, inside, looking past the scene and looking away from it.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -16,11 +18,11 @@ from raytracer_amd import abi, synth
 T = abi.RT_TILE
 
 
-def scene_box(sd):
-    """Bounds of the triangles of a scene made of untransformed triangles only."""
-    pts = np.concatenate([np.asarray(sd.triangles[k], np.float64) for k in ("p1", "p2", "p3")] +
-                         [np.asarray(sd.smooth_triangles[k], np.float64) for k in ("p1", "p2", "p3")])
-    return pts.min(0), pts.max(0)
+def primitive_boxes(sd):
+    """Bounds of every triangle of a scene made of untransformed triangles only: (n, 3) lows and highs."""
+    p = [np.concatenate([np.asarray(sd.triangles[k], np.float64), np.asarray(sd.smooth_triangles[k], np.float64)]) for k in ("p1", "p2", "p3")]
+    pts = np.stack(p, axis=1)                       # (n, 3 vertices, 3)
+    return pts.min(1), pts.max(1)
 
 
 def rays_of_tile(cam, width, height, spp_root, tx, ty, per_edge=9):
@@ -67,32 +69,45 @@ def test_no_ray_of_a_tile_left_out_comes_near_the_scene(seed):
     for arr in (sd.triangles, sd.smooth_triangles):
         arr["mod"]["trans"][:] = np.eye(4, dtype=np.float32).reshape(16)
         arr["mod"]["inv_trans"][:] = np.eye(4, dtype=np.float32).reshape(16)
-    lo, hi = scene_box(sd)
+    los, his = primitive_boxes(sd)
     some_left_out = False
+    left_out, left_out_by_the_scene_box = 0, 0
     for pos, at in VIEWS:
         sd.camera = {"pos": np.array(pos, np.float32), "up": np.array([0, 1, 0], np.float32),
                      "right": np.array([1.3333, 0, 0], np.float32), "look_at": np.array(at, np.float32)}
         for (w, h, spp_root) in ((200, 150, 1), (333, 257, 2)):
             with ra.Scene(sd, host_only=True) as sc:
                 live = sc.tiles_live(w, h, spp_root * spp_root)
+            os.environ["RT_CULL_FINE"] = "0"
+            try:
+                with ra.Scene(sd, host_only=True) as sc:
+                    coarse = sc.tiles_live(w, h, spp_root * spp_root)
+            finally:
+                os.environ.pop("RT_CULL_FINE", None)
+            assert not (live & ~coarse).any()            # the finer test only ever leaves out more
+            left_out += int((~live.astype(bool)).sum()); left_out_by_the_scene_box += int((~coarse.astype(bool)).sum())
             tiles_x, tiles_y = (w + T - 1) // T, (h + T - 1) // T
             assert len(live) == tiles_x * tiles_y
             for k, flag in enumerate(live):
                 o, d = rays_of_tile(sd.camera, w, h, spp_root, k % tiles_x, k // tiles_x)
                 if not flag:
                     some_left_out = True
-                    assert not hits_box(o, d, lo, hi, 2e-3).any(), (pos, at, w, h, k)
+                    for lo, hi in zip(los, his):
+                        assert not hits_box(o, d, lo, hi, 2e-3).any(), (pos, at, w, h, k)
                 else:
                     pass        # a live tile may well miss everything: the test errs on the side of tracing
     assert some_left_out
+    assert left_out > left_out_by_the_scene_box      # sparse triangles: many tiles see the scene's box and no triangle's
 
 
-def test_everything_is_live_from_inside_and_with_planes():
+def test_everything_is_live_with_planes_and_without_the_finer_test_from_inside(monkeypatch):
     sd = synth.random_scene(44, n_planes=0)
     sd.camera = {"pos": np.array([0.1, 0.1, 0.2], np.float32), "up": np.array([0, 1, 0], np.float32),
                  "right": np.array([1.3333, 0, 0], np.float32), "look_at": np.array([0, 0, -1], np.float32)}
+    monkeypatch.setenv("RT_CULL_FINE", "0")
     with ra.Scene(sd, host_only=True) as sc:
-        assert sc.tiles_live(320, 200).all()
+        assert sc.tiles_live(320, 200).all()             # the camera sits inside the scene's box
+    monkeypatch.delenv("RT_CULL_FINE")
     sd = synth.random_scene(44, n_planes=1)          # a plane is tested for every ray (kernel.cu:189-196)
     sd.camera["pos"] = np.array([0, 1, 40], np.float32)
     sd.camera["look_at"] = np.array([0, 1, 100], np.float32)
