@@ -16,7 +16,9 @@ FIELDS = ("VGPRs", "AGPRs", "VGPRs Spill", "SGPRs Spill", "TotalSGPRs", "Scratch
 
 
 def resources(src, extra=()):
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-I" + os.path.join(ROOT, "include"),
+    # the library's own flags (csrc/Makefile): -O3, and -Os on top of it for the translation unit with the kernels
+    level = ["-O3", "-Os"] if os.path.basename(src) == "rt_render.hip" else ["-O3"]
+    cmd = ["/opt/rocm/bin/hipcc", *level, "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-I" + os.path.join(ROOT, "include"),
            "-I" + CSRC, "--offload-arch=gfx950", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", *extra, src, "-o", "/dev/null"]
     err = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC).stderr
     out, cur = [], None
