@@ -124,14 +124,23 @@ struct MatKeyHash {
 struct MatTable {
    std::vector<rt_material> materials;
    std::unordered_map<MatKey, uint32_t, MatKeyHash> index;
+   MatKey last_key;
+   uint32_t last_id = 0;
+   bool have_last = false;
    uint32_t id_of(const rt_material &m)
    {
       MatKey k; memset(&k, 0, sizeof k); k.m = m;
+      /* (a mesh's triangles share one material: the one asked for last is the likely answer) */
+      if (have_last && k == last_key) return last_id;
+      uint32_t id;
       auto it = index.find(k);
-      if (it != index.end()) return it->second;
-      uint32_t id = (uint32_t)materials.size();
-      materials.push_back(m);
-      index[k] = id;
+      if (it != index.end()) id = it->second;
+      else {
+         id = (uint32_t)materials.size();
+         materials.push_back(m);
+         index[k] = id;
+      }
+      last_key = k; last_id = id; have_last = true;
       return id;
    }
 };
@@ -626,6 +635,36 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
       box_centers.resize((size_t)n);
       for (int i = 0; i < n; i++) box_centers[(size_t)i] = box_center(b.boxes[(size_t)i]);
    }
+   std::vector<rt_bvh_node> filter;
+   int filter_depth = 0;
+   int filter_min = RT_FILTER_MIN_PRIMS;
+   if (const char *e = getenv("RT_FILTER_MIN_PRIMS")) { if (atoi(e) >= 2) filter_min = atoi(e); }     /* tests lower it to put small scenes through the filter */
+   const bool want_filter = n >= filter_min && !(flags & (RT_SCENE_FAST_BVH | RT_SCENE_GPU_BVH | RT_SCENE_NO_FILTER));
+   auto build_filter = [&]() {
+      try {
+      std::vector<int32_t> ids((size_t)n);
+      for (int i = 0; i < n; i++) ids[(size_t)i] = i;
+      std::vector<TreeNode> pool;
+      pool.reserve((size_t)(2 * n));
+      int levels = 0; while ((1 << levels) < n) levels++;
+      SahBuilder sb{b.boxes, box_centers, ids, pool};
+      /* no deeper than the traversal stack's share of LDS where the primitive count allows that: a tree that pushed
+       * the stack into global memory would cost more than its better splits win */
+      int budget = levels + 2 > RT_FILTER_DEPTH ? levels + 2 : RT_FILTER_DEPTH;
+      int root_node = sb.build(0, n, budget, 3);
+      if (pool[(size_t)root_node].prim < 0) {
+         flatten_tree(pool, root_node, filter, &filter_depth);      /* (widened once the thread is joined, below) */
+      }
+      } catch (...) { filter.clear(); filter_depth = 0; }      /* out of memory: the scene goes without */
+   };
+   std::thread filter_thread;
+   struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{filter_thread};
+   bool filter_inline = false;
+   if (want_filter) {
+      try { filter_thread = std::thread(build_filter); } catch (...) { filter_inline = true; }
+   }
+
+   /* (worked out while the second tree is built: only its widening, after the join, needs it) */
    /* How far from the origin of the coordinates a ray may start and still use the second tree.  The two trees' box tests
     * round the differences they take from a ray's origin differently (their boxes differ), by a few units in the last place
     * of the origin's coordinates -- 1e-4 per subtraction for a light a thousand units from a scene of size one.  The second
@@ -657,45 +696,6 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
    }
    float origin_pad = origin_reach * 9.5367431640625e-7f;      /* 2^-20 */
    if (const char *e = getenv("RT_ORIGIN_MARGIN")) origin_pad *= (float)atof(e);      /* (for measurements: what the margin costs) */
-   std::vector<rt_bvh_node> filter;
-   int filter_depth = 0;
-   int filter_min = RT_FILTER_MIN_PRIMS;
-   if (const char *e = getenv("RT_FILTER_MIN_PRIMS")) { if (atoi(e) >= 2) filter_min = atoi(e); }     /* tests lower it to put small scenes through the filter */
-   const bool want_filter = n >= filter_min && !(flags & (RT_SCENE_FAST_BVH | RT_SCENE_GPU_BVH | RT_SCENE_NO_FILTER));
-   auto build_filter = [&]() {
-      try {
-      std::vector<int32_t> ids((size_t)n);
-      for (int i = 0; i < n; i++) ids[(size_t)i] = i;
-      std::vector<TreeNode> pool;
-      pool.reserve((size_t)(2 * n));
-      int levels = 0; while ((1 << levels) < n) levels++;
-      SahBuilder sb{b.boxes, box_centers, ids, pool};
-      /* no deeper than the traversal stack's share of LDS where the primitive count allows that: a tree that pushed
-       * the stack into global memory would cost more than its better splits win */
-      int budget = levels + 2 > RT_FILTER_DEPTH ? levels + 2 : RT_FILTER_DEPTH;
-      int root_node = sb.build(0, n, budget, 3);
-      if (pool[(size_t)root_node].prim < 0) {
-         flatten_tree(pool, root_node, filter, &filter_depth);
-         /* Every box of this tree contains the reference's own (padded) boxes of the primitives below it.  It is
-          * widened by 1e-4 plus a few units in the last place of its coordinates, far more than the rounding of the
-          * box test, so that a ray the reference's test lets into a primitive's own box is never turned away here. */
-         for (size_t k = 0; k < filter.size(); k++) {
-            float *v = filter[k].lmin;      /* lmin, lmax, rmin, rmax */
-            for (int j = 0; j < 12; j++) {
-               const float pad = 1e-4f + 8e-6f * std::fabs(v[j]) + origin_pad;
-               const bool is_max = (j / 3) & 1;
-               v[j] = is_max ? v[j] + pad : v[j] - pad;
-            }
-         }
-      }
-      } catch (...) { filter.clear(); filter_depth = 0; }      /* out of memory: the scene goes without */
-   };
-   std::thread filter_thread;
-   struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{filter_thread};
-   bool filter_inline = false;
-   if (want_filter) {
-      try { filter_thread = std::thread(build_filter); } catch (...) { filter_inline = true; }
-   }
 
    std::vector<rt_bvh_node> flat;
    int32_t root = RT_ROOT_EMPTY;
@@ -771,6 +771,18 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
 
    if (filter_inline) build_filter();
    if (filter_thread.joinable()) filter_thread.join();
+   /* Every box of the second tree contains the reference's own (padded) boxes of the primitives below it.  It is
+    * widened by 1e-4 plus a few units in the last place of its coordinates, far more than the rounding of the
+    * box test, so that a ray the reference's test lets into a primitive's own box is never turned away there; and by
+    * the margin for the rays' origins. */
+   for (size_t k = 0; k < filter.size(); k++) {
+      float *v = filter[k].lmin;      /* lmin, lmax, rmin, rmax */
+      for (int j = 0; j < 12; j++) {
+         const float pad = 1e-4f + 8e-6f * std::fabs(v[j]) + origin_pad;
+         const bool is_max = (j / 3) & 1;
+         v[j] = is_max ? v[j] + pad : v[j] - pad;
+      }
+   }
 
    std::vector<rt_dev_light> lights((size_t)d->n_lights);
    for (int i = 0; i < d->n_lights; i++) {
