@@ -850,7 +850,44 @@ extern "C" int rt_render(rt_scene *scene, const rt_render_params *params, uint8_
    hipError_t e = all_tiles ? hipSuccess : hipMemset(d_out, 0, bytes);
    int rc = e == hipSuccess ? render_impl(scene, &p, VIEW_FRAME, d_out, nullptr, nullptr, nullptr, nullptr, stats) : RT_ERR_HIP;
    if (rc == RT_OK) {
-      e = hipMemcpy(out_host, d_out, bytes, hipMemcpyDeviceToHost);   /* kernel.cu:759-760 */
+      /* kernel.cu:759-760.  A copy into pageable memory goes through the runtime's own staging at about half the
+       * bus's rate (a 1080p frame: 0.45 ms); a scene that is asked for a second frame gets a pinned buffer for it
+       * (a one-frame scene would pay more for the buffer than it wins). */
+      s->host_frames++;
+      if (s->host_frames >= 2 && bytes > s->h_frame_cap && bytes <= ((size_t)256 << 20) && rt_env_int("RT_PINNED_FRAME", 1, true)) {
+         if (s->h_frame) { (void)hipHostFree(s->h_frame); s->h_frame = nullptr; s->h_frame_cap = 0; }
+         if (hipHostMalloc(&s->h_frame, bytes, hipHostMallocDefault) == hipSuccess) s->h_frame_cap = bytes;
+         else { s->h_frame = nullptr; (void)hipGetLastError(); }      /* (no pinned memory to be had: the plain copy, then) */
+         if (s->h_frame && !s->copy_ev_ok) {
+            bool ok = true;
+            for (int k = 0; k < 4 && ok; k++) {
+               ok = hipEventCreateWithFlags(&s->copy_ev[k], hipEventDisableTiming) == hipSuccess;
+               if (!ok) for (int j = 0; j < k; j++) (void)hipEventDestroy(s->copy_ev[j]);
+            }
+            s->copy_ev_ok = ok;
+            if (!ok) { (void)hipGetLastError(); (void)hipHostFree(s->h_frame); s->h_frame = nullptr; s->h_frame_cap = 0; }
+         }
+      }
+      if (s->h_frame && s->h_frame_cap >= bytes && s->copy_ev_ok) {
+         const int parts = bytes >= ((size_t)1 << 20) ? 4 : 1;
+         const size_t part = ((bytes + (size_t)parts - 1) / (size_t)parts + 4095) & ~(size_t)4095;
+         int issued = 0;
+         for (int k = 0; k < parts && e == hipSuccess; k++) {
+            const size_t off = (size_t)k * part;
+            if (off >= bytes) break;
+            const size_t len = bytes - off < part ? bytes - off : part;
+            e = hipMemcpyAsync((char *)s->h_frame + off, (const char *)d_out + off, len, hipMemcpyDeviceToHost, nullptr);
+            if (e == hipSuccess) e = hipEventRecord(s->copy_ev[k], nullptr);
+            if (e == hipSuccess) issued++;
+         }
+         for (int k = 0; k < issued; k++) {
+            const size_t off = (size_t)k * part;
+            const size_t len = bytes - off < part ? bytes - off : part;
+            hipError_t w = hipEventSynchronize(s->copy_ev[k]);
+            if (w != hipSuccess) { if (e == hipSuccess) e = w; continue; }      /* (every part issued is waited for, whatever happens) */
+            if (e == hipSuccess) memcpy(out_host + off, (const char *)s->h_frame + off, len);
+         }
+      } else e = hipMemcpy(out_host, d_out, bytes, hipMemcpyDeviceToHost);
       if (e != hipSuccess) { rt_set_error("frame copy failed: %s", hipGetErrorString(e)); rc = RT_ERR_HIP; }
    }
    return rc;

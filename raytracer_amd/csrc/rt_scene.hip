@@ -43,6 +43,8 @@ extern "C" void rt_scene_destroy(rt_scene *s)
    if (s->h_stats) (void)hipHostFree(s->h_stats);
    if (s->d_lists) (void)hipFree(s->d_lists);
    if (s->d_frame) (void)hipFree(s->d_frame);
+   if (s->h_frame) (void)hipHostFree(s->h_frame);
+   if (s->copy_ev_ok) for (hipEvent_t e : s->copy_ev) (void)hipEventDestroy(e);
    if (s->d_spill) (void)hipFree(s->d_spill);
    if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
    if (s->d_tile_order) (void)hipFree(s->d_tile_order);
@@ -349,7 +351,9 @@ static int scene_upload(rt_scene *s, int flags)
       const size_t bytes = sizeof(StackEntry) * (size_t)(rt_stack_depth(s) - RT_LDS_STACK) * (size_t)s->trace_blocks * RT_BLOCK;
       if (hipMalloc((void **)&s->d_spill, bytes) != hipSuccess) { rt_set_error("allocation of %zu bytes of traversal stack failed", bytes); rt_scene_destroy(s); return RT_ERR_HIP; }
    }
-   {
+   if (s->own_stream) {
+      /* (only a scene that runs its frames on a stream of its own needs one: the first streams a process creates cost
+       * milliseconds each, more than a small scene's whole first frame) */
       bool ok = hipStreamCreateWithFlags(&s->chain, hipStreamNonBlocking) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&s->ev_begin, hipEventDisableTiming) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&s->ev_end, hipEventDisableTiming) == hipSuccess;

@@ -55,6 +55,10 @@ struct rt_scene {
    float node_factor;       /* queue entries per primary ray the chain kernel gets room for; grows when a frame overflows */
    StackEntry *d_spill;     /* trees deeper than RT_LDS_STACK: the stack entries beyond LDS, (depth - RT_LDS_STACK) x lanes of a full launch */
    void *d_frame; size_t frame_cap;   /* rt_render's device copy of the frame, kept from call to call */
+   /* rt_render's way back to the caller's (pageable) frame, from a scene's second such call on: through a pinned buffer
+    * of the scene's own, in parts, each part copied on to the caller while the next one crosses the bus */
+   void *h_frame = nullptr; size_t h_frame_cap = 0; unsigned host_frames = 0;
+   hipEvent_t copy_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool copy_ev_ok = false;
    uint2 *d_lists;          /* the waves' lists of spawned rays (k_trace): list_waves rings of list_cap entries */
    unsigned list_cap, list_waves;
    /* Tiles are started costliest first, by the previous frame's depth of the bounce trees per tile: the waves that

@@ -79,3 +79,23 @@ def test_host_only_scene_cannot_be_cloned():
     with ra.Scene(sd, host_only=True) as sc:
         with pytest.raises(Exception):
             sc.clone(0)
+
+
+def test_scene_with_a_stream_of_its_own_renders_the_same_bytes(monkeypatch):
+    """RT_OWN_STREAM=1 (read when a scene is created): the frame's kernels run on a stream the scene creates, bracketed by
+    events on the caller's; a scene without the knob creates no stream at all."""
+    sd = ra.SceneData.load(os.path.join(GOLDEN, "scenes", "recurse_simp2.npz"))
+    with ra.Scene(sd) as sc:
+        want, st = sc.render(320, 240, 4, abi.RT_COOK_TORRANCE, abi.RT_JITTER_HASH, seed=5)
+    monkeypatch.setenv("RT_OWN_STREAM", "1")
+    with ra.Scene(sd) as sc:
+        got, st_own = sc.render(320, 240, 4, abi.RT_COOK_TORRANCE, abi.RT_JITTER_HASH, seed=5)
+        again, _ = sc.render(320, 240, 4, abi.RT_COOK_TORRANCE, abi.RT_JITTER_HASH, seed=5)
+        twin = sc.clone()
+        try:
+            third, _ = twin.render(320, 240, 4, abi.RT_COOK_TORRANCE, abi.RT_JITTER_HASH, seed=5)
+        finally:
+            twin.close()
+    assert got.tobytes() == want.tobytes() and again.tobytes() == want.tobytes() and third.tobytes() == want.tobytes()
+    for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract"):
+        assert st[k] == st_own[k], k
