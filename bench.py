@@ -437,8 +437,8 @@ def end_to_end(ra, abi, first_ms, steady_ms):
         sc.close()
         t4 = time.perf_counter()
         out["cold_call_800x600"][name] = {"wall_ms": round(dt * 1e3, 2),
-                                          "parts_ms": {"scene_create": round((t2 - t1) * 1e3, 2), "of_it_host_tree_builds": round(info["ms_build_host"], 2),
-                                                       "of_it_upload_and_allocations": round(info["ms_upload"], 2),
+                                          "parts_ms": {"scene_create": round((t2 - t1) * 1e3, 2), "of_it_records_and_first_tree": round(info["ms_build_host"], 2),
+                                                       "of_it_upload_allocations_and_wait_for_second_tree": round(info["ms_upload"], 2),
                                                        "first_frame_call_with_copy_back": round((t3 - t2) * 1e3, 2), "of_it_on_the_device": round(st["ms_total"], 3),
                                                        "scene_destroy": round((t4 - t3) * 1e3, 2)},
                                           "reference_whole_program_s": README_WALL_S[name],

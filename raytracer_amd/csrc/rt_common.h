@@ -90,9 +90,10 @@ typedef struct rt_flat_scene {
    /* Sphere::intersects (Sphere.h:42-66) takes the difference of two products of the size (distance to the sphere)^2:
     * what it reports as the hit lies off the sphere by up to about 2^-22 * distance^2 / radius (more for a sphere
     * squeezed by its transform).  The largest of 1 / radius over the scene's spheres, in world units, with that
-    * squeeze folded in; 0 for a scene without spheres.  See RayCtx::wide. */
+    * squeeze folded in; 0 for a scene without spheres. */
    float sphere_coeff;
    float origin_reach;      /* rays that start within this many units of the origin of the coordinates, on every axis, may use the second tree (its boxes are widened for them) */
+   void *pending_filter;    /* RT_FLATTEN_DEFER_FILTER: the second tree's thread is still at work (filter_nodes is empty until rt_flat_scene_finish); NULL otherwise */
 } rt_flat_scene;
 
 #ifdef __cplusplus
@@ -104,6 +105,11 @@ int rt_flatten_scene(const rt_scene_desc *desc, rt_flat_scene *out);
 /* flags: RT_SCENE_FAST_BVH builds the opt-in surface-area-heuristic tree instead of the reference's */
 int rt_flatten_scene_ex(const rt_scene_desc *desc, int flags, rt_flat_scene *out);
 void rt_flat_scene_free(rt_flat_scene *fs);
+/* (internal flag of rt_flatten_scene_ex, beside the RT_SCENE_* ones) the second tree's thread runs on after the call
+ * returns; rt_flat_scene_finish waits for it and fills in filter_nodes, n_filter_nodes and filter_depth.  Every copy
+ * of the struct made before that call must be made again after it. */
+#define RT_FLATTEN_DEFER_FILTER (1 << 30)
+int rt_flat_scene_finish(rt_flat_scene *fs);
 void rt_set_error(const char *fmt, ...);
 /* device-side linear BVH over n >= 2 boxes (rt_lbvh.hip) */
 int rt_lbvh_build(const float *boxes_host, int n, rt_bvh_node **nodes_out, int32_t **order_out, int *depth_out, float *ms_out);

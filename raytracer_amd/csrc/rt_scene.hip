@@ -136,7 +136,8 @@ extern "C" int rt_scene_create(const rt_scene_desc *desc, int device, int flags,
 
    if (!rt_env_int("RT_MISS_FILTER", 1, true)) flags |= RT_SCENE_NO_FILTER;      /* for A/B runs; frames are the same either way */
    auto t0 = std::chrono::steady_clock::now();
-   int st = rt_flatten_scene_ex(desc, flags, &s->host);
+   /* (the second tree's thread runs on while the rest of the scene is prepared and copied: scene_upload waits for it) */
+   int st = rt_flatten_scene_ex(desc, flags | RT_FLATTEN_DEFER_FILTER, &s->host);
    if (st != RT_OK) { delete s; return st; }
    if ((flags & RT_SCENE_GPU_BVH) && s->host.n_prims > 1) {
       rt_bvh_node *nodes = nullptr; int32_t *order = nullptr; int depth = 0; float ms = 0.0f;
@@ -199,17 +200,25 @@ static int scene_upload(rt_scene *s, int flags)
    for (size_t k = 0; k < np_; k++) { d_prims[k] = h.prims[ids[k]]; d_xforms[k] = h.xforms[ids[k]]; d_shades[k] = h.shades[ids[k]]; }
    /* one node array: the tree the rays are answered from, then (if the scene has one) the miss filter's tree, its
     * internal child references moved behind the first tree's records */
-   const size_t n_tree = (size_t)(h.n_nodes > 0 ? h.n_nodes : 0), n_filter = (size_t)(h.n_filter_nodes > 0 ? h.n_filter_nodes : 0);
+   /* (a scene fresh from rt_scene_create may still be building its second tree on a thread of its own: that tree has one
+    * node less than the scene has primitives -- or does not come at all -- and its records are filled in last, below,
+    * after everything else has been prepared and copied) */
+   const bool filter_pending = h.pending_filter != nullptr;
+   const size_t n_tree = (size_t)(h.n_nodes > 0 ? h.n_nodes : 0);
+   size_t n_filter = filter_pending ? (np_ > 1 ? np_ - 1 : 0) : (size_t)(h.n_filter_nodes > 0 ? h.n_filter_nodes : 0);
    std::vector<rt_bvh_node> d_nodes(n_tree + n_filter);
-   for (size_t k = 0; k < d_nodes.size(); k++) {
-      const bool in_filter = k >= n_tree;
-      d_nodes[k] = in_filter ? h.filter_nodes[k - n_tree] : h.nodes[k];
-      int32_t *child[2] = {&d_nodes[k].left, &d_nodes[k].right};
-      for (int c = 0; c < 2; c++) {
-         if (*child[c] < 0) *child[c] = ~pos_of[(size_t)~*child[c]];
-         else if (in_filter) *child[c] += (int32_t)n_tree;
+   auto place_nodes = [&](size_t first, size_t last) {
+      for (size_t k = first; k < last; k++) {
+         const bool in_filter = k >= n_tree;
+         d_nodes[k] = in_filter ? s->host.filter_nodes[k - n_tree] : s->host.nodes[k];
+         int32_t *child[2] = {&d_nodes[k].left, &d_nodes[k].right};
+         for (int c = 0; c < 2; c++) {
+            if (*child[c] < 0) *child[c] = ~pos_of[(size_t)~*child[c]];
+            else if (in_filter) *child[c] += (int32_t)n_tree;
+         }
       }
-   }
+   };
+   place_nodes(0, filter_pending ? n_tree : d_nodes.size());
    s->prim_ids_host = ids;
    /* where each leaf hangs in the reference's tree, for walking the path from the root down to one leaf */
    std::vector<int32_t> leaf_parent(n_filter > 0 ? np_ : 0, 0);
@@ -263,14 +272,20 @@ static int scene_upload(rt_scene *s, int flags)
        * of hundreds of megabytes is not staged a second time on the host: its arrays go one by one) */
       const bool staged = s->dev_bytes <= ((size_t)64 << 20);
       std::vector<char> stage(staged ? s->dev_bytes : 0);
+      /* (of the node array only the first tree's records, while the second tree is still being built) */
+      const size_t nodes_now = filter_pending ? sizeof(rt_bvh_node) * n_tree : sizes[0];
       for (int k = 0; k < N_ARR; k++) {
-         if (!sizes[k]) continue;
-         if (staged) { memcpy(stage.data() + off[k], src[k], sizes[k]); continue; }
-         e = hipMemcpy((char *)s->dev_blob + off[k], src[k], sizes[k], hipMemcpyHostToDevice);
+         const size_t len = k == 0 ? nodes_now : sizes[k];
+         if (!len) continue;
+         if (staged) { memcpy(stage.data() + off[k], src[k], len); continue; }
+         e = hipMemcpy((char *)s->dev_blob + off[k], src[k], len, hipMemcpyHostToDevice);
          if (e != hipSuccess) { rt_set_error("scene upload failed: %s", hipGetErrorString(e)); rt_scene_destroy(s); return RT_ERR_HIP; }
       }
       if (staged) {
-         e = hipMemcpy(s->dev_blob, stage.data(), s->dev_bytes, hipMemcpyHostToDevice);
+         if (filter_pending) {
+            e = nodes_now ? hipMemcpy(s->dev_blob, stage.data(), nodes_now, hipMemcpyHostToDevice) : hipSuccess;
+            if (e == hipSuccess && s->dev_bytes > off[1]) e = hipMemcpy((char *)s->dev_blob + off[1], stage.data() + off[1], s->dev_bytes - off[1], hipMemcpyHostToDevice);
+         } else e = hipMemcpy(s->dev_blob, stage.data(), s->dev_bytes, hipMemcpyHostToDevice);
          if (e != hipSuccess) { rt_set_error("scene upload failed: %s", hipGetErrorString(e)); rt_scene_destroy(s); return RT_ERR_HIP; }
       }
    }
@@ -359,6 +374,20 @@ static int scene_upload(rt_scene *s, int flags)
       ok = ok && hipEventCreateWithFlags(&s->ev_end, hipEventDisableTiming) == hipSuccess;
       if (!ok) { rt_set_error("stream / event creation failed"); rt_scene_destroy(s); return RT_ERR_HIP; }
       s->streams_ok = true;
+   }
+   if (filter_pending) {
+      /* the second tree, now: its records behind the first tree's -- or, if it did not come, a scene without one */
+      (void)rt_flat_scene_finish(&s->host);
+      if (s->host_owner) s->host_owner->flat = s->host;
+      const size_t got = (size_t)(s->host.n_filter_nodes > 0 ? s->host.n_filter_nodes : 0);
+      if (got == n_filter && got > 0) {
+         place_nodes(n_tree, n_tree + n_filter);
+         e = hipMemcpy((char *)s->dev_blob + sizeof(rt_bvh_node) * n_tree, d_nodes.data() + n_tree, sizeof(rt_bvh_node) * n_filter, hipMemcpyHostToDevice);
+         if (e != hipSuccess) { rt_set_error("scene upload failed: %s", hipGetErrorString(e)); rt_scene_destroy(s); return RT_ERR_HIP; }
+      } else {
+         n_filter = 0;
+         s->d.filter_root = RT_ROOT_EMPTY; s->d.verify_jump = 0; s->guide_ok = false;
+      }
    }
    e = hipDeviceSynchronize();
    if (e != hipSuccess) { rt_set_error("scene upload failed: %s", hipGetErrorString(e)); rt_scene_destroy(s); return RT_ERR_HIP; }

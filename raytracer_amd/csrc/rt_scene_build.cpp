@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <new>
 #include <thread>
+#include <memory>
 #include <vector>
 
 namespace {
@@ -483,6 +484,60 @@ struct SahBuilder {
    }
 };
 
+/* The second tree over `n` primitive boxes, unwidened (root 0); empty if it cannot be had (one primitive, or out of
+ * memory: the scene goes without). */
+void build_filter_tree(const std::vector<Box3> &boxes, const std::vector<F3> &centers, int n, std::vector<rt_bvh_node> &filter, int &filter_depth)
+{
+   try {
+      std::vector<int32_t> ids((size_t)n);
+      for (int i = 0; i < n; i++) ids[(size_t)i] = i;
+      std::vector<TreeNode> pool;
+      pool.reserve((size_t)(2 * n));
+      int levels = 0; while ((1 << levels) < n) levels++;
+      SahBuilder sb{boxes, centers, ids, pool};
+      /* no deeper than the traversal stack's share of LDS where the primitive count allows that: a tree that pushed
+       * the stack into global memory would cost more than its better splits win */
+      int budget = levels + 2 > RT_FILTER_DEPTH ? levels + 2 : RT_FILTER_DEPTH;
+      int root_node = sb.build(0, n, budget, 3);
+      if (pool[(size_t)root_node].prim < 0) flatten_tree(pool, root_node, filter, &filter_depth);
+   } catch (...) { filter.clear(); filter_depth = 0; }
+}
+
+/* Every box of the second tree contains the reference's own (padded) boxes of the primitives below it.  It is
+ * widened by 1e-4 plus a few units in the last place of its coordinates, far more than the rounding of the
+ * box test, so that a ray the reference's test lets into a primitive's own box is never turned away there; and by
+ * the margin for the rays' origins.  A tree with a bound out of the box test's range is dropped. */
+void widen_filter_tree(std::vector<rt_bvh_node> &filter, int &filter_depth, float origin_pad)
+{
+   for (size_t k = 0; k < filter.size(); k++) {
+      float *v = filter[k].lmin;      /* lmin, lmax, rmin, rmax */
+      for (int j = 0; j < 12; j++) {
+         const float pad = 1e-4f + 8e-6f * std::fabs(v[j]) + origin_pad;
+         const bool is_max = (j / 3) & 1;
+         v[j] = is_max ? v[j] + pad : v[j] - pad;
+      }
+   }
+   for (size_t k = 0; k < filter.size(); k++) {
+      const float *v = filter[k].lmin;
+      bool bad = false;
+      for (int j = 0; j < 12; j++) if (!(std::fabs(v[j]) <= 1.099511627776e12f)) bad = true;
+      if (bad) { filter.clear(); filter_depth = 0; break; }
+   }
+}
+
+/* A second tree still being built when rt_flatten_scene_ex returns (RT_FLATTEN_DEFER_FILTER): the thread, what it
+ * reads and what it writes.  rt_flat_scene_finish joins it. */
+struct PendingFilter {
+   std::vector<Box3> boxes;
+   std::vector<F3> centers;
+   int n = 0;
+   float origin_pad = 0.0f;
+   std::vector<rt_bvh_node> nodes;
+   int depth = 0;
+   std::thread worker;
+   ~PendingFilter() { if (worker.joinable()) worker.join(); }
+};
+
 /* a material's texture reference must name a texture whose pixels are there */
 /* the same test without the message (what the filling threads use) */
 bool tex_known(const rt_scene_desc *d, int tex_id)
@@ -640,27 +695,21 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
    int filter_min = RT_FILTER_MIN_PRIMS;
    if (const char *e = getenv("RT_FILTER_MIN_PRIMS")) { if (atoi(e) >= 2) filter_min = atoi(e); }     /* tests lower it to put small scenes through the filter */
    const bool want_filter = n >= filter_min && !(flags & (RT_SCENE_FAST_BVH | RT_SCENE_GPU_BVH | RT_SCENE_NO_FILTER));
-   auto build_filter = [&]() {
-      try {
-      std::vector<int32_t> ids((size_t)n);
-      for (int i = 0; i < n; i++) ids[(size_t)i] = i;
-      std::vector<TreeNode> pool;
-      pool.reserve((size_t)(2 * n));
-      int levels = 0; while ((1 << levels) < n) levels++;
-      SahBuilder sb{b.boxes, box_centers, ids, pool};
-      /* no deeper than the traversal stack's share of LDS where the primitive count allows that: a tree that pushed
-       * the stack into global memory would cost more than its better splits win */
-      int budget = levels + 2 > RT_FILTER_DEPTH ? levels + 2 : RT_FILTER_DEPTH;
-      int root_node = sb.build(0, n, budget, 3);
-      if (pool[(size_t)root_node].prim < 0) {
-         flatten_tree(pool, root_node, filter, &filter_depth);      /* (widened once the thread is joined, below) */
-      }
-      } catch (...) { filter.clear(); filter_depth = 0; }      /* out of memory: the scene goes without */
-   };
+   auto build_filter = [&]() { build_filter_tree(b.boxes, box_centers, n, filter, filter_depth); };
    std::thread filter_thread;
    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{filter_thread};
    bool filter_inline = false;
-   if (want_filter) {
+   /* (a caller that has work of its own to do before it needs the second tree lets the thread run on past this call) */
+   std::unique_ptr<PendingFilter> pending;
+   if (want_filter && (flags & RT_FLATTEN_DEFER_FILTER)) {
+      try {
+         pending.reset(new PendingFilter);
+         pending->boxes = b.boxes; pending->centers = box_centers; pending->n = n;
+         PendingFilter *pf = pending.get();
+         pending->worker = std::thread([pf]() { build_filter_tree(pf->boxes, pf->centers, pf->n, pf->nodes, pf->depth); });
+      } catch (...) { pending.reset(); }      /* (no memory or no thread for that: built within this call, then) */
+   }
+   if (want_filter && !pending) {
       try { filter_thread = std::thread(build_filter); } catch (...) { filter_inline = true; }
    }
 
@@ -771,18 +820,8 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
 
    if (filter_inline) build_filter();
    if (filter_thread.joinable()) filter_thread.join();
-   /* Every box of the second tree contains the reference's own (padded) boxes of the primitives below it.  It is
-    * widened by 1e-4 plus a few units in the last place of its coordinates, far more than the rounding of the
-    * box test, so that a ray the reference's test lets into a primitive's own box is never turned away there; and by
-    * the margin for the rays' origins. */
-   for (size_t k = 0; k < filter.size(); k++) {
-      float *v = filter[k].lmin;      /* lmin, lmax, rmin, rmax */
-      for (int j = 0; j < 12; j++) {
-         const float pad = 1e-4f + 8e-6f * std::fabs(v[j]) + origin_pad;
-         const bool is_max = (j / 3) & 1;
-         v[j] = is_max ? v[j] + pad : v[j] - pad;
-      }
-   }
+   widen_filter_tree(filter, filter_depth, origin_pad);
+   if (pending) pending->origin_pad = origin_pad;
 
    std::vector<rt_dev_light> lights((size_t)d->n_lights);
    for (int i = 0; i < d->n_lights; i++) {
@@ -819,11 +858,6 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
       for (int j = 0; j < 12; j++)
          if (!(std::fabs(v[j]) <= 1.099511627776e12f)) out->bounds_in_range = 0;
    }
-   for (size_t k = 0; k < filter.size(); k++) {
-      const float *v = filter[k].lmin;
-      for (int j = 0; j < 12; j++)
-         if (!(std::fabs(v[j]) <= 1.099511627776e12f)) { filter.clear(); filter_depth = 0; break; }    /* out of the box test's range: no filter */
-   }
    out->n_filter_nodes = (int32_t)filter.size(); out->filter_depth = filter_depth;
    out->filter_nodes = copy_out(filter);
    out->nodes = copy_out(flat);
@@ -855,12 +889,29 @@ extern "C" int rt_flatten_scene_ex(const rt_scene_desc *d, int flags, rt_flat_sc
       out->texels = copy_out(texels);
       out->n_texels = texels.size() / 4;
    }
+   out->pending_filter = pending.release();
+   return RT_OK;
+}
+
+/* The second tree of a scene flattened with RT_FLATTEN_DEFER_FILTER: waits for its thread and puts the tree where a
+ * call without the flag would have put it.  Does nothing for any other scene, or the second time. */
+extern "C" int rt_flat_scene_finish(rt_flat_scene *fs)
+{
+   if (!fs || !fs->pending_filter) return RT_OK;
+   std::unique_ptr<PendingFilter> pf((PendingFilter *)fs->pending_filter);
+   fs->pending_filter = nullptr;
+   if (pf->worker.joinable()) pf->worker.join();
+   widen_filter_tree(pf->nodes, pf->depth, pf->origin_pad);
+   free(fs->filter_nodes);
+   fs->filter_nodes = copy_out(pf->nodes);
+   fs->n_filter_nodes = (int32_t)pf->nodes.size(); fs->filter_depth = pf->depth;
    return RT_OK;
 }
 
 extern "C" void rt_flat_scene_free(rt_flat_scene *fs)
 {
    if (!fs) return;
+   delete (PendingFilter *)fs->pending_filter;      /* (a second tree nobody waited for: its thread is joined here) */
    free(fs->nodes); free(fs->filter_nodes); free(fs->prims); free(fs->xforms); free(fs->shades); free(fs->planes);
    free(fs->materials); free(fs->lights); free(fs->leaf_order); free(fs->tex_info); free(fs->texels); free(fs->prim_boxes);
    memset(fs, 0, sizeof *fs);

@@ -8,6 +8,23 @@
 #include <cstring>
 #include <vector>
 #include <cmath>
+/* the second tree left to its thread past the call: waited for and compared with the one built within the call, and
+ * once more freed without anybody waiting */
+static bool deferred_tree_matches(const rt_scene_desc *d, const rt_flat_scene &fs, const char *name)
+{
+   rt_flat_scene late, dropped;
+   if (rt_flatten_scene_ex(d, RT_FLATTEN_DEFER_FILTER, &late) != RT_OK) return false;
+   if (rt_flatten_scene_ex(d, RT_FLATTEN_DEFER_FILTER, &dropped) != RT_OK) { rt_flat_scene_free(&late); return false; }
+   rt_flat_scene_free(&dropped);
+   const bool was_pending = late.pending_filter != nullptr;
+   (void)rt_flat_scene_finish(&late); (void)rt_flat_scene_finish(&late);
+   const bool same = late.pending_filter == nullptr && late.n_filter_nodes == fs.n_filter_nodes && late.filter_depth == fs.filter_depth &&
+                     (fs.n_filter_nodes == 0 || memcmp(late.filter_nodes, fs.filter_nodes, sizeof(rt_bvh_node) * (size_t)fs.n_filter_nodes) == 0);
+   printf("%s deferred: pending %d same %d\n", name, (int)was_pending, (int)same);
+   rt_flat_scene_free(&late);
+   return same;
+}
+
 int main(int argc, char **argv)
 {
    for (int a = 1; a < argc; a++) {
@@ -17,6 +34,7 @@ int main(int argc, char **argv)
          rt_flat_scene fs;
          int rc = rt_flatten_scene_ex(d, flags, &fs);
          printf("%s flags %d: rc %d prims %d nodes %d filter %d depth %d reach %g\n", argv[a], flags, rc, fs.n_prims, fs.n_nodes, fs.n_filter_nodes, fs.tree_depth, fs.origin_reach);
+         if (rc == RT_OK && flags == 0 && !deferred_tree_matches(d, fs, argv[a])) { printf("DEFERRED TREE DIFFERS\n"); return 1; }
          if (rc == RT_OK) rt_flat_scene_free(&fs);
       }
       rt_scene_desc_free(d);
@@ -39,6 +57,7 @@ int main(int argc, char **argv)
          rt_flat_scene fs;
          int rc = rt_flatten_scene_ex(&d, flags, &fs);
          printf("synthetic flags %d: rc %d prims %d nodes %d filter %d materials %d\n", flags, rc, fs.n_prims, fs.n_nodes, fs.n_filter_nodes, fs.n_materials);
+         if (rc == RT_OK && flags == 0 && !deferred_tree_matches(&d, fs, "synthetic")) { printf("DEFERRED TREE DIFFERS\n"); return 1; }
          if (rc == RT_OK) rt_flat_scene_free(&fs);
       }
    }

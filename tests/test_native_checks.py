@@ -71,3 +71,4 @@ def test_host_scene_build_under_sanitizers(tmp_path):
     assert out.returncode == 0, out.stderr[-4000:]
     assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr and "LeakSanitizer" not in out.stderr, out.stderr[-4000:]
     assert "synthetic flags 0: rc 0 prims 70000 nodes 69999 filter 69999 materials 977" in out.stdout, out.stdout[-2000:]
+    assert "synthetic deferred: pending 1 same 1" in out.stdout, out.stdout[-2000:]
