@@ -108,6 +108,10 @@ enum { ST_SHADOW_SKIPPED = 0, ST_REFLECT, ST_REFRACT, ST_SHADE_NODES,
 /* Statistics counters are replicated RT_STAT_REPL times (blocks spread over the replicas, the host
  * sums them) and bumped once per wave, so that counting does not serialise the kernels on one word. */
 #define RT_STAT_REPL 32
+/* the host's pinned copy of the counters, rounded up to whole kilobytes; behind it, in the same allocation, the
+ * costs (two words) and the start order (one word) of up to RT_PINNED_TILES tiles (a 2560x1440 frame has 3 600) */
+#define RT_STATS_BYTES_PADDED ((((size_t)ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long)) + 1023) & ~(size_t)1023)
+#define RT_PINNED_TILES 4096
 __device__ __forceinline__ void stat_add(unsigned long long *stats, int which, unsigned long long v)
 {
    atomicAdd(&stats[which * RT_STAT_REPL + (blockIdx.x & (RT_STAT_REPL - 1))], v);

@@ -511,15 +511,24 @@ static int render_impl(rt_scene *s, const rt_render_params *p, int view, void *o
       if (track_cost && n_sel > s->order_cap) {
          if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
          if (s->d_tile_order) (void)hipFree(s->d_tile_order);
-         if (s->h_tile_cost) (void)hipHostFree(s->h_tile_cost);
-         if (s->h_tile_order) (void)hipHostFree(s->h_tile_order);
+         if (s->h_tile_cost && !s->tiles_in_block) (void)hipHostFree(s->h_tile_cost);
+         if (s->h_tile_order && !s->tiles_in_block) (void)hipHostFree(s->h_tile_order);
          s->d_tile_cost = s->h_tile_cost = nullptr; s->d_tile_order = s->h_tile_order = nullptr; s->order_cap = 0; s->order_valid = false; s->order_dirty = true;
-         const size_t bytes = sizeof(unsigned) * (size_t)n_sel;
+         s->tiles_in_block = false;
+         const long long room = n_sel <= RT_PINNED_TILES ? RT_PINNED_TILES : n_sel;
+         const size_t bytes = sizeof(unsigned) * (size_t)room;
          /* two cost words per tile: its longest chain and the sum of its chains */
          HIP_TRY(hipMalloc((void **)&s->d_tile_cost, 2 * bytes)); HIP_TRY(hipMalloc((void **)&s->d_tile_order, bytes));
-         HIP_TRY(hipHostMalloc((void **)&s->h_tile_cost, 2 * bytes, hipHostMallocDefault));
-         HIP_TRY(hipHostMalloc((void **)&s->h_tile_order, bytes, hipHostMallocDefault));
-         s->order_cap = n_sel;
+         if (room == RT_PINNED_TILES) {
+            /* (the usual frame: the room behind the statistics, pinned with them when the scene was made) */
+            s->h_tile_cost = (unsigned *)((char *)s->h_stats + RT_STATS_BYTES_PADDED);
+            s->h_tile_order = (int *)(s->h_tile_cost + 2 * (size_t)RT_PINNED_TILES);
+            s->tiles_in_block = true;
+         } else {
+            HIP_TRY(hipHostMalloc((void **)&s->h_tile_cost, 2 * bytes, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void **)&s->h_tile_order, bytes, hipHostMallocDefault));
+         }
+         s->order_cap = room;
       }
       bool have_order = track_cost && s->order_valid && memcmp(key, s->order_key, sizeof key) == 0;
       /* Tiles no ray can meet anything through are left out of the launch: the start order lists the others first, and

@@ -48,8 +48,8 @@ extern "C" void rt_scene_destroy(rt_scene *s)
    if (s->d_spill) (void)hipFree(s->d_spill);
    if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
    if (s->d_tile_order) (void)hipFree(s->d_tile_order);
-   if (s->h_tile_cost) (void)hipHostFree(s->h_tile_cost);
-   if (s->h_tile_order) (void)hipHostFree(s->h_tile_order);
+   if (s->h_tile_cost && !s->tiles_in_block) (void)hipHostFree(s->h_tile_cost);
+   if (s->h_tile_order && !s->tiles_in_block) (void)hipHostFree(s->h_tile_order);
    for (hipEvent_t e : s->timing_events) (void)hipEventDestroy(e);
    if (s->streams_ok) {
       (void)hipStreamDestroy(s->chain);
@@ -359,7 +359,7 @@ static int scene_upload(rt_scene *s, int flags)
 
    if (hipMalloc((void **)&s->d_ctr, RT_CTR_WORDS * sizeof(unsigned long long)) != hipSuccess ||
        hipMalloc((void **)&s->d_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long)) != hipSuccess ||
-       hipHostMalloc((void **)&s->h_stats, ST_COUNT * RT_STAT_REPL * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+       hipHostMalloc((void **)&s->h_stats, RT_STATS_BYTES_PADDED + 3 * sizeof(unsigned) * (size_t)RT_PINNED_TILES, hipHostMallocDefault) != hipSuccess) {
       rt_set_error("allocation of queue counters failed"); rt_scene_destroy(s); return RT_ERR_HIP;
    }
    if (rt_stack_depth(s) > RT_LDS_STACK) {

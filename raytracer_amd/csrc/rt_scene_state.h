@@ -51,7 +51,7 @@ struct rt_scene {
    Arena arena;             /* per-frame queues; grown on demand, reused across frames */
    unsigned long long *d_ctr;    /* work counters of the chunk in flight: RT_CTR_WORDS words (see ChunkCtr) */
    unsigned long long *d_stats;
-   unsigned long long *h_stats;  /* pinned */
+   unsigned long long *h_stats;  /* pinned; room for RT_PINNED_TILES tiles' costs and order behind it */
    float node_factor;       /* queue entries per primary ray the chain kernel gets room for; grows when a frame overflows */
    StackEntry *d_spill;     /* trees deeper than RT_LDS_STACK: the stack entries beyond LDS, (depth - RT_LDS_STACK) x lanes of a full launch */
    void *d_frame; size_t frame_cap;   /* rt_render's device copy of the frame, kept from call to call */
@@ -66,6 +66,8 @@ struct rt_scene {
    unsigned *d_tile_cost, *h_tile_cost;   /* h_: pinned */
    int *d_tile_order, *h_tile_order;      /* h_: pinned */
    long long order_cap;                   /* tiles the four arrays have room for */
+   bool tiles_in_block = false;           /* h_tile_cost and h_tile_order lie behind h_stats in its allocation (frames of up to RT_PINNED_TILES tiles: one pinned
+                                           * allocation per scene instead of three -- freeing one costs up to 0.2 ms) */
    long long order_key[6];                /* width, height, samples, tile_first, tile_stride, tiles of the frame the order is for */
    bool can_bounce;                       /* some material reflects or refracts: without one every ray tree is a single node */
    bool order_valid, order_dirty;         /* dirty: h_tile_order differs from what d_tile_order holds */
