@@ -232,7 +232,9 @@ def counted_shape(ct):
             "lane_utilisation_leaf_steps": round(npt / max(1, 64 * ct["wave_leaf_steps"]), 3),
             "wave_time_refill": round(ct["wave_time_refill"], 3), "wave_time_node": round(ct["wave_time_node"], 3), "wave_time_leaf": round(ct["wave_time_leaf"], 3),
             "hits_certified": ct["hits_certified"], "hits_contested": ct["hits_contested"], "hits_guided": ct["hits_guided"], "hits_unreached": ct["hits_unreached"],
-            "shadows_certified": ct["shadows_certified"], "second_tree": ct["second_tree"]}
+            "shadows_certified": ct["shadows_certified"], "second_tree": ct["second_tree"],
+            "wave_node_steps_with_rays_in_both_trees": round(ct["wave_steps_both_trees"] / max(1, ct["wave_node_steps"]), 3),
+            "wave_node_steps_in_second_tree_only": round(ct["wave_steps_second_tree_only"] / max(1, ct["wave_node_steps"]), 3)}
 
 
 def terrain_roofline(s4, c4, gbs, fetched, info):

@@ -197,6 +197,9 @@ typedef struct rt_stats {
    /* RT_SCENE_COUNTERS: of hits_contested, the rays whose walk of the reference's tree left out every subtree without one
     * of the few primitives that can change its outcome (the others made the walk in full) */
    uint64_t hits_guided;
+   /* RT_SCENE_COUNTERS: of wave_node_steps, those in which the wave held rays in both trees, and those in which every
+    * ray it moved was in the second tree (the rest: rays in the reference's tree only) */
+   uint64_t wave_steps_both_trees, wave_steps_second_tree_only;
 } rt_stats;
 
 typedef struct rt_scene_info {

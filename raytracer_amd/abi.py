@@ -97,7 +97,8 @@ class Stats(C.Structure):
                 ("wave_time_refill", C.c_float), ("wave_time_node", C.c_float), ("wave_time_leaf", C.c_float), ("second_tree", C.c_int32),
                 ("max_ray_steps", C.c_uint64), ("max_spawn_list", C.c_uint64),
                 ("hits_certified", C.c_uint64), ("hits_contested", C.c_uint64), ("hits_unreached", C.c_uint64),
-                ("shadows_certified", C.c_uint64), ("primaries_culled", C.c_uint64), ("shadows_unneeded", C.c_uint64), ("hits_guided", C.c_uint64)]
+                ("shadows_certified", C.c_uint64), ("primaries_culled", C.c_uint64), ("shadows_unneeded", C.c_uint64), ("hits_guided", C.c_uint64),
+                ("wave_steps_both_trees", C.c_uint64), ("wave_steps_second_tree_only", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

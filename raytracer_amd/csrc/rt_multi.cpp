@@ -388,7 +388,7 @@ int core_render(Core *m, const rt_render_params *params, uint8_t *out_host, void
       total.node_visits_shadow += s.node_visits_shadow; total.prim_tests_shadow += s.prim_tests_shadow;
       total.tie_events_shadow += s.tie_events_shadow;
       total.wave_node_steps += s.wave_node_steps; total.wave_leaf_steps += s.wave_leaf_steps;
-      total.hits_certified += s.hits_certified; total.hits_contested += s.hits_contested; total.hits_unreached += s.hits_unreached; total.hits_guided += s.hits_guided;
+      total.hits_certified += s.hits_certified; total.hits_contested += s.hits_contested; total.hits_unreached += s.hits_unreached; total.hits_guided += s.hits_guided; total.wave_steps_both_trees += s.wave_steps_both_trees; total.wave_steps_second_tree_only += s.wave_steps_second_tree_only;
       total.shadows_certified += s.shadows_certified;
       total.primaries_culled += s.primaries_culled;
       total.shadows_unneeded += s.shadows_unneeded;

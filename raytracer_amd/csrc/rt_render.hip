@@ -779,6 +779,7 @@ static int render_impl(rt_scene *s, const rt_render_params *p, int view, void *o
    st.lane_steps_at_leaf = sum_stat(s->h_stats, ST_LEAF_WAIT); st.lane_steps_no_ray = sum_stat(s->h_stats, ST_NO_RAY);
    st.wave_refills = sum_stat(s->h_stats, ST_REFILLS);
    st.hits_certified = sum_stat(s->h_stats, ST_CERT_OK); st.hits_contested = sum_stat(s->h_stats, ST_CERT_RIVAL); st.hits_guided = sum_stat(s->h_stats, ST_GUIDED);
+   st.wave_steps_both_trees = sum_stat(s->h_stats, ST_STEPS_BOTH); st.wave_steps_second_tree_only = sum_stat(s->h_stats, ST_STEPS_SECOND_ONLY);
    st.hits_unreached = sum_stat(s->h_stats, ST_CERT_UNREACHED);
    st.shadows_certified = sum_stat(s->h_stats, ST_SHADOW_CERT);
    st.shadows_unneeded = sum_stat(s->h_stats, ST_SHADOW_UNNEEDED);
@@ -802,7 +803,7 @@ static int render_impl(rt_scene *s, const rt_render_params *p, int view, void *o
       s->last_frame.g = g; s->last_frame.np = (long long)n_sel * per_tile; s->last_frame.hits_offset = last_hits_offset;
       s->last_frame.culled = culled_frame; s->last_frame.n_sel = n_sel; s->last_frame.valid = true;
    }
-   st.second_tree = filter_kinds;
+   st.second_tree = s->d.filter_root != RT_ROOT_EMPTY ? filter_kinds : 0;      /* (a scene without the tree: none, whatever the choice would be) */
    st.max_ray_steps = s->h_stats[ST_MAX_RAY_STEPS * RT_STAT_REPL];
    st.max_spawn_list = s->h_stats[ST_MAX_LIST * RT_STAT_REPL];
    st.attempts = attempts;

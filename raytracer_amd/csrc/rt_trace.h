@@ -427,6 +427,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
    unsigned n_unneeded = 0;                             /* OUT_CHAIN: feelers that stopped after their own-surface test because their answer cannot matter */
    unsigned n_shadow_cert = 0;                          /* COUNT only: feelers reported "shadowed" from the second tree and one path of the reference's */
    unsigned n_cert = 0, n_rival = 0, n_unreached = 0;   /* COUNT only: how this lane's closest-hit rays left the second tree with a hit */
+   unsigned n_steps_both = 0, n_steps_second = 0;        /* COUNT only, the same in every lane: node steps with rays in both trees / in the second tree only */
    unsigned n_guided = 0;                               /* COUNT only: of n_rival, those that went on guided */
    unsigned n_leafwait = 0, n_noray = 0, n_refills = 0;   /* COUNT only: node steps this lane sat out at a leaf / without a ray; refills of the wave */
 
@@ -1022,6 +1023,10 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
             if (COUNT) {
                wn++; if (active) ray_steps++;
                if (cur < 0) { if (cur == RT_CUR_IDLE) n_noray++; else n_leafwait++; }
+               if (TWO) {
+                  const unsigned long long in_second = __ballot(in_node && (mode & MODE_FILTER) != 0), in_first = __ballot(in_node && (mode & MODE_FILTER) == 0);
+                  if (in_second && in_first) n_steps_both++; else if (in_second) n_steps_second++;
+               }
             }
             if (in_node) node_step(variant_tag);
          }
@@ -1197,6 +1202,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WAV
       stat_add(stats, ST_NO_RAY, (unsigned long long)n_noray);
       if (lane == 0) {
          stat_add(stats, ST_REFILLS, (unsigned long long)n_refills);
+         stat_add(stats, ST_STEPS_BOTH, (unsigned long long)n_steps_both); stat_add(stats, ST_STEPS_SECOND_ONLY, (unsigned long long)n_steps_second);
          stat_add(stats, ST_CLK_REFILL, clk_refill); stat_add(stats, ST_CLK_NODE, clk_node); stat_add(stats, ST_CLK_LEAF, clk_leaf);
          stat_add(stats, ST_CLK_WAVE, wall_clock64() - clock_start);
          stat_add(stats, ST_WAVE_NODE_STEPS, (unsigned long long)wn);

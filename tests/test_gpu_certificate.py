@@ -228,3 +228,18 @@ def test_feelers_certified_in_crowded_scenes_and_on_the_flake():
     sd = ra.SceneData.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes", "balls2.npz"))
     st = both_ways(sd, 320, 180, 1, oracle=False)
     assert st["shadows_certified"] > st["rays_shadow"] // 10
+
+
+def test_wave_steps_are_split_by_tree():
+    """RT_SCENE_COUNTERS: the wave node steps with rays in both trees and in the second tree only are counted, and a scene
+    without the second tree has neither."""
+    sd = ra.SceneData.load(os.path.join(os.path.dirname(__file__), "golden", "scenes", "balls2.npz"))
+    with ra.Scene(sd, counters=True) as sc:
+        for _ in range(7):
+            _, st = sc.render(320, 240, 1)
+    assert st["second_tree"] != 0
+    assert 0 < st["wave_steps_both_trees"] and 0 < st["wave_steps_second_tree_only"]
+    assert st["wave_steps_both_trees"] + st["wave_steps_second_tree_only"] <= st["wave_node_steps"]
+    with ra.Scene(sd, counters=True, miss_filter=False) as sc:
+        _, st = sc.render(320, 240, 1)
+    assert st["second_tree"] == 0 and st["wave_steps_both_trees"] == 0 and st["wave_steps_second_tree_only"] == 0

@@ -28,3 +28,7 @@ print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in ct.items()})
 print("lane utilisation node %.3f leaf %.3f; fetches per ray %.1f; node steps per wave %.0f, leaf steps per wave %.0f, refills per wave %.0f" % (
     nv / (64.0 * max(1, ct["wave_node_steps"])), npt / (64.0 * max(1, ct["wave_leaf_steps"])), (nv + npt) / ct["rays_total"],
     ct["wave_node_steps"] / 4096.0, ct["wave_leaf_steps"] / 4096.0, ct["wave_refills"] / 4096.0), flush=True)
+if ct["wave_node_steps"]:
+    both, second = ct["wave_steps_both_trees"], ct["wave_steps_second_tree_only"]
+    print("wave node steps with rays in both trees %.3f, in the second tree only %.3f, in the reference's only %.3f" % (
+        both / ct["wave_node_steps"], second / ct["wave_node_steps"], 1.0 - (both + second) / ct["wave_node_steps"]), flush=True)
