@@ -26,8 +26,27 @@ def load(name):
 
 SMALL = ["simple", "simple_reflect", "simple_reflect2", "simple_refract", "simple_spec", "simple_tri", "simple_cam",
          "recurse_simp", "recurse_simp2", "transforms", "box", "final1", "final2", "cornell", "valentine",
-         "ugly_part", "evil"]
-MESH = ["bunny_small_tris", "bunny", "dragon_large_tris", "balls2", "iceBot", "bunny_obj"]
+         "ugly_part", "evil",
+         "rgb", "rgb2", "rgbT", "test", "test2", "test3", "recuse_simp2", "recurses", "donut"]
+MESH = ["bunny_small_tris", "bunny", "dragon_large_tris", "balls2", "iceBot", "bunny_obj",
+        "blitz", "gnarly", "miniShark", "shark", "monkey", "sphere_bunny_small"]
+
+
+def test_every_scene_fixture_is_rendered_against_the_oracle():
+    """tests/golden/scenes holds one fixture per scene file of the reference (and bunny_obj); each is in one of the lists."""
+    have = sorted(os.path.splitext(f)[0] for f in os.listdir(os.path.join(GOLDEN, "scenes")))
+    assert sorted(SMALL + MESH + ["blitzcrank", "moo"]) == have      # (blitzcrank, the textured one, and moo, the empty file, have tests of their own below)
+
+
+def test_empty_scene_file_is_rejected_for_its_missing_camera():
+    """moo.pov is an empty file: no objects, no lights, no camera.  The reference dereferences the camera unchecked
+    (kernel.cu:716); here the frame call says so."""
+    sd = load("moo")
+    assert sd.n_bvh_prims == 0 and len(sd.planes) == 0 and len(sd.lights) == 0
+    with ra.Scene(sd, device=0) as sc:
+        with pytest.raises(ra.RaytracerError) as e:
+            sc.render(16, 16, 1)
+        assert e.value.code == abi.RT_ERR_NO_CAMERA
 
 
 def check_scene(name, w, h, shading=abi.RT_PHONG, samples=1, jitter=abi.RT_JITTER_NONE, seed=0, rgb_tol=RGB_TOL):
