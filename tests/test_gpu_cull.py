@@ -47,7 +47,8 @@ def look_from(sd, pos, look_at=(0.0, 0.0, 0.0), right=1.3333):
     return sd
 
 
-@pytest.mark.parametrize("name", ["bunny", "dragon_large_tris", "balls2", "iceBot", "valentine", "recurse_simp2", "cornell", "blitzcrank"])
+@pytest.mark.parametrize("name", ["bunny", "dragon_large_tris", "balls2", "iceBot", "valentine", "recurse_simp2", "cornell", "blitzcrank",
+                                  "gnarly", "miniShark", "monkey", "blitz", "test2", "test3"])      # (the last six: scenes without planes, where tiles can be left out)
 def test_fixture_scenes_same_bytes(name):
     path = os.path.join(G, name + ".npz")
     if not os.path.exists(path):

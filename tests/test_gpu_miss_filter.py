@@ -50,7 +50,7 @@ def both_ways(sd, w, h, spp, shading, jitter=abi.RT_JITTER_HASH, seed=5):
 
 
 @pytest.mark.parametrize("name", ["cornell", "balls2", "bunny", "iceBot", "dragon_large_tris", "box", "transforms", "final2", "recurse_simp2",
-                                  "simple_refract", "valentine"])
+                                  "simple_refract", "valentine", "gnarly", "shark", "miniShark", "monkey", "blitz", "sphere_bunny_small", "recurses", "donut"])
 @pytest.mark.parametrize("shading", [abi.RT_PHONG, abi.RT_COOK_TORRANCE])
 def test_frames_equal_with_and_without_filter(name, shading):
     sd = ra.SceneData.load(os.path.join(G, name + ".npz"))
