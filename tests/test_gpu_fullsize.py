@@ -210,3 +210,23 @@ def test_other_scenes_full_size_against_oracle(name):
     assert st["rays_shadow"] + st["shadow_skipped"] == c["rays_shadow"]
     diff = np.abs(frame[:, :, :3].astype(int) - ref["rgba"][:, :, :3].astype(int)).max(axis=2)
     assert (diff <= 1).mean() >= 0.999, f"{name}: {(diff > 1).sum()} pixels off by more than 1"
+
+
+@pytest.mark.parametrize("name", ["balls2", "iceBot", "gnarly", "dragon_large_tris", "blitzcrank"])
+def test_other_scenes_full_size_cook_torrance_four_samples(name):
+    """The headline's settings (Cook-Torrance, 2x2 strata, hash jitter) on other scenes, warm."""
+    sd = ra.SceneData.load(os.path.join(GOLDEN, "scenes", name + ".npz"))
+    with ra.Scene(sd) as sc:
+        for _ in range(6):
+            frame, st = sc.render(W, H, 4, abi.RT_COOK_TORRANCE, abi.RT_JITTER_HASH, seed=2)
+        prim, t = sc.frame_primary_hits(W, H, 4)
+    osc = orclib.OracleScene(sd)
+    ref = osc.render(W, H, 4, abi.RT_COOK_TORRANCE, abi.RT_JITTER_HASH, 2, want_samples=False)
+    osc.close()
+    assert np.array_equal(prim, ref["prim"])
+    assert np.array_equal(t.view(np.uint32), ref["t"].view(np.uint32))
+    c = ref["counters"]
+    assert (st["rays_primary"], st["rays_reflect"], st["rays_refract"]) == (c["rays_primary"], c["rays_reflect"], c["rays_refract"])
+    assert st["rays_shadow"] + st["shadow_skipped"] == c["rays_shadow"]
+    diff = np.abs(frame[:, :, :3].astype(int) - ref["rgba"][:, :, :3].astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.999, f"{name}: {(diff > 1).sum()} pixels off by more than 1"
