@@ -204,3 +204,28 @@ def test_million_triangles_256_lights_in_chunks():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_million_triangles_at_the_configuration_s_own_size():
+    """The same scene at the size the configuration names: 3840x2160, 16 samples per pixel (16.7 G rays per frame, two
+    launches).  Size-independent properties only (see above): the same bytes and counts whatever the chunking, counts that add up."""
+    sd = synth.terrain(1000, 500)
+    w, h, spp = 3840, 2160, 16
+    keep = os.environ.get("RT_CHUNK_TILES")
+    try:
+        with ra.Scene(sd, fast_bvh=True) as sc:
+            whole, st = sc.render(w, h, spp, abi.RT_PHONG, abi.RT_JITTER_HASH)
+            os.environ["RT_CHUNK_TILES"] = "1500"
+            chunked, st_c = sc.render(w, h, spp, abi.RT_PHONG, abi.RT_JITTER_HASH)
+        assert st["launches_trace"] >= 2 and st_c["launches_trace"] == 6                     # 8 160 tiles in chunks of 1 500
+        assert chunked.tobytes() == whole.tobytes()
+        for k in ("rays_primary", "rays_shadow", "rays_reflect", "shade_nodes", "shadow_skipped", "rays_total"):
+            assert st_c[k] == st[k], k
+        assert st["rays_primary"] == w * h * spp
+        assert st["rays_shadow"] + st["shadow_skipped"] == 256 * st["shade_nodes"]
+        assert st["rays_total"] > 16_000_000_000
+    finally:
+        if keep is None:
+            os.environ.pop("RT_CHUNK_TILES", None)
+        else:
+            os.environ["RT_CHUNK_TILES"] = keep
