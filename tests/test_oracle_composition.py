@@ -1,8 +1,8 @@
 """How the oracle's composition -- traversal order, tie rule, shadeObject recursion, bounce and shadow decisions -- is
 pinned beyond its leaves (which are bit-exact against the reference's own classes, test_oracle_goldens.py).
 
-1. Ray counts.  A frame's ray count depends on every hit, miss, spawn and shadow decision of every pixel.  The survey
-   of the reference compiled the reference's own kernel.cu logic on the host and recorded the counts of seven scenes
+1. Ray counts.  A frame's ray count depends on every hit, miss, spawn and shadow decision of every pixel.  A host
+   build of the reference's own kernel.cu logic, made before this code existed, recorded the counts of seven scenes
    (no jitter, Phong, 800x600; simple.pov 640x480).  The oracle reproduces all seven exactly when Sphere.h:55,63 is
    read as that host build read it (unqualified sqrt(float) bound to ::sqrt(double), the expression evaluated in
    double), and the five scenes without that ambiguity exactly either way.  With the binary32 reading that nvcc's
